@@ -1,0 +1,127 @@
+"""ctypes front end of the CPU oracle (oracle/dqp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under diff-qp-mpc_amd/ imports this module.
+
+numpy in / numpy out, fp64, batch-major contiguous.  `build()` compiles the C file with the
+Makefile next to it (gcc + OpenMP).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libdqp_oracle.so")
+_lib = None
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "dqp_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.dqp_oracle_max_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None and a.size else ctypes.cast(None, _dp)
+
+
+def max_threads():
+    return int(lib().dqp_oracle_max_threads())
+
+
+def qp_forward(Q, p, G, h, A, b, eps=1e-12, notImprovedLim=3, maxIter=20, nthreads=0):
+    """batch.py:46-208 restated.  Returns dict(zhat, lam, nu, slack, iters, best_resid)."""
+    Q, p, G, h = _c(Q), _c(p), _c(G), _c(h)
+    B, nz = p.shape
+    nineq = h.shape[1]
+    neq = 0 if A is None or np.size(A) == 0 else A.shape[1]
+    A = _c(A) if neq else None
+    b = _c(b) if neq else None
+    zhat = np.empty((B, nz)); lam = np.empty((B, nineq)); slack = np.empty((B, nineq))
+    nu = np.empty((B, neq)); res = np.empty(B)
+    it = ctypes.c_int(0)
+    rc = lib().dqp_oracle_qp_forward(
+        B, nz, nineq, neq, _p(Q), _p(p), _p(G), _p(h), _p(A), _p(b),
+        ctypes.c_double(eps), notImprovedLim, maxIter,
+        _p(zhat), _p(lam), _p(nu), _p(slack), ctypes.byref(it), _p(res), nthreads)
+    if rc != 0:
+        raise RuntimeError("oracle qp_forward failed rc=%d" % rc)
+    return dict(zhat=zhat, lam=lam, nu=nu, slack=slack, iters=it.value, best_resid=res)
+
+
+def qp_backward(Q, G, A, zhat, lam, nu, slack, dl_dzhat, nthreads=0):
+    """qp.py:128-183 restated, per-sample gradients (no mean over broadcast params)."""
+    Q, G = _c(Q), _c(G)
+    B, nz = zhat.shape
+    nineq = lam.shape[1]
+    neq = 0 if A is None or np.size(A) == 0 else A.shape[1]
+    A = _c(A) if neq else None
+    dQ = np.empty((B, nz, nz)); dp = np.empty((B, nz)); dG = np.empty((B, nineq, nz))
+    dh = np.empty((B, nineq)); dA = np.empty((B, neq, nz)); db = np.empty((B, neq))
+    rc = lib().dqp_oracle_qp_backward(
+        B, nz, nineq, neq, _p(Q), _p(G), _p(A), _p(_c(zhat)), _p(_c(lam)),
+        _p(_c(nu)) if neq else _p(None), _p(_c(slack)), _p(_c(dl_dzhat)),
+        _p(dQ), _p(dp), _p(dG), _p(dh), _p(dA), _p(db), nthreads)
+    if rc != 0:
+        raise RuntimeError("oracle qp_backward failed rc=%d" % rc)
+    return dict(dQ=dQ, dp=dp, dG=dG, dh=dh, dA=dA, db=db)
+
+
+def dense_forward(Q, p, G, h, A, b, eps=1e-12, notImprovedLim=3, maxIter=20, nthreads=0):
+    """qp.py:219-237 + batch_LU.py:29-201 restated."""
+    Q, p, G, h, A, b = _c(Q), _c(p), _c(G), _c(h), _c(A), _c(b)
+    B, nz = p.shape
+    nineq, neq = h.shape[1], b.shape[1]
+    N = nz + 2 * nineq + neq
+    zhat = np.empty((B, nz)); lam = np.empty((B, nineq)); slack = np.empty((B, nineq))
+    nu = np.empty((B, neq)); K = np.empty((B, N, N))
+    it = ctypes.c_int(0)
+    rc = lib().dqp_oracle_dense_forward(
+        B, nz, nineq, neq, _p(Q), _p(p), _p(G), _p(h), _p(A), _p(b),
+        ctypes.c_double(eps), notImprovedLim, maxIter,
+        _p(zhat), _p(lam), _p(nu), _p(slack), _p(K), ctypes.byref(it), nthreads)
+    if rc != 0:
+        raise RuntimeError("oracle dense_forward failed rc=%d" % rc)
+    return dict(zhat=zhat, lam=lam, nu=nu, slack=slack, K=K, iters=it.value)
+
+
+def dense_backward(K, zhat, lam, nu, dl_dzhat, nthreads=0):
+    """qp.py:239-270 restated."""
+    K = _c(K)
+    B, nz = zhat.shape
+    nineq, neq = lam.shape[1], nu.shape[1]
+    dQ = np.empty((B, nz, nz)); dp = np.empty((B, nz)); dG = np.empty((B, nineq, nz))
+    dh = np.empty((B, nineq)); dA = np.empty((B, neq, nz)); db = np.empty((B, neq))
+    rc = lib().dqp_oracle_dense_backward(
+        B, nz, nineq, neq, _p(K), _p(_c(zhat)), _p(_c(lam)), _p(_c(nu)), _p(_c(dl_dzhat)),
+        _p(dQ), _p(dp), _p(dG), _p(dh), _p(dA), _p(db), nthreads)
+    if rc != 0:
+        raise RuntimeError("oracle dense_backward failed rc=%d" % rc)
+    return dict(dQ=dQ, dp=dp, dG=dG, dh=dh, dA=dA, db=db)
+
+
+def expand(a, B, nd):
+    """Reference broadcasting rule (util.py:36-43): one fewer dim == shared over the batch."""
+    a = np.asarray(a, dtype=np.float64)
+    return a if a.ndim == nd else np.broadcast_to(a, (B,) + a.shape).copy()

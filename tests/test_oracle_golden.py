@@ -1,0 +1,88 @@
+"""Pins the CPU oracle (oracle/dqp_oracle.c) to the reference's own outputs.
+
+The fixtures in tests/golden/ were produced by importing the reference
+(tests/golden/make_golden.py); here the C restatement must reproduce them.
+Tolerances (fp64): zhat/lam/nu/slack rtol 1e-7 atol 1e-9; gradients rtol 1e-5 atol 1e-7 --
+both far inside the level at which the reference's two own solvers agree with each other
+(3e-13 on zhat, 5e-6 on gradients).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def expanded_inputs(g):
+    B = g["zhat"].shape[0]
+    out = {}
+    for k, nd in (("Q", 3), ("p", 2), ("G", 3), ("h", 2), ("A", 3), ("b", 2)):
+        out[k] = oracle.expand(g["in_" + k], B, nd)
+    return B, out
+
+
+def test_fixture_inventory():
+    assert len(CASES) >= 10, CASES
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_qp_forward_matches_reference(name):
+    g = load(name)
+    B, d = expanded_inputs(g)
+    o = oracle.qp_forward(d["Q"], d["p"], d["G"], d["h"], d["A"], d["b"])
+    np.testing.assert_allclose(o["zhat"], g["zhat"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(o["lam"], g["lam"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(o["slack"], g["slack"], rtol=1e-6, atol=1e-9)
+    if g["nu"].shape[1]:
+        np.testing.assert_allclose(o["nu"], g["nu"], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("tag", ["ones", "rand"])
+def test_qp_backward_matches_reference(name, tag):
+    g = load(name)
+    B, d = expanded_inputs(g)
+    neq = g["nu"].shape[1]
+    o = oracle.qp_backward(d["Q"], d["G"], d["A"], g["zhat"], g["lam"], g["nu"], g["slack"],
+                           g["ct_" + tag])
+    for k, nd in (("Q", 3), ("p", 2), ("G", 3), ("h", 2), ("A", 3), ("b", 2)):
+        if neq == 0 and k in "Ab":
+            continue
+        ref = g["d%s_%s" % (k, tag)]
+        got = o["d" + k]
+        if g["in_" + k].ndim != nd:          # shared parameter -> .mean(0)  (qp.py:160-178)
+            got = got.mean(0)
+        np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-7, err_msg="d" + k)
+
+
+DENSE = [c for c in CASES if "dense_zhat" in np.load(os.path.join(GOLDEN, c + ".npz")).files]
+
+
+@pytest.mark.parametrize("name", DENSE)
+def test_dense_forward_backward_matches_reference(name):
+    g = load(name)
+    B, d = expanded_inputs(g)
+    o = oracle.dense_forward(d["Q"], d["p"], d["G"], d["h"], d["A"], d["b"])
+    np.testing.assert_allclose(o["zhat"], g["dense_zhat"], rtol=1e-7, atol=1e-9)
+    for tag in ("ones", "rand"):
+        gr = oracle.dense_backward(o["K"], o["zhat"], o["lam"], o["nu"], g["ct_" + tag])
+        for k in "QpGhAb":
+            np.testing.assert_allclose(gr["d" + k], g["dense_d%s_%s" % (k, tag)],
+                                       rtol=1e-5, atol=1e-7, err_msg="dense d" + k)
+
+
+def test_oracle_thread_count_invariant():
+    g = load("R_small_b5")
+    B, d = expanded_inputs(g)
+    a = oracle.qp_forward(d["Q"], d["p"], d["G"], d["h"], d["A"], d["b"], nthreads=1)
+    b = oracle.qp_forward(d["Q"], d["p"], d["G"], d["h"], d["A"], d["b"], nthreads=4)
+    assert np.array_equal(a["zhat"], b["zhat"]) and a["iters"] == b["iters"]
