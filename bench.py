@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: QPs/sec for one forward + one backward of the differentiable
+batched QP solver on the BASELINE.json metric config (batch=4096, n_state=3, n_ctrl=3, T=5 ->
+nz=30, nineq=30, neq=15; random dense family R of SURVEY.md §8d), fp64.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one pass of the hot path over one batch resident in HBM: dqp_qp_forward followed
+by dqp_qp_backward (cotangent = ones), called through the C ABI on torch's current stream.
+With N > 1 (launched by torch.distributed.run, one rank per GPU) every rank solves its own
+4096-QP shard (weak scaling, no data-path collective in the timed region except the single
+all_gather of the solved zhat batch that BASELINE.json's north_star names).
+
+Prints ONE JSON line (rank 0) with `roofline` (forward kernel, HIP-event timed, algorithmic
+bytes of SURVEY.md §8d) and `cpu_baseline` (the C oracle, a port of the reference algorithm,
+timed on this host's cores on the same workload).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+B_PER_GPU = 4096
+NZ, NINEQ, NEQ = 30, 30, 15
+# algorithmic elements per QP
+FWD_ELEMS = (NZ * NZ + NZ + NINEQ * NZ + NINEQ + NEQ * NZ + NEQ) + (NZ + 2 * NINEQ + NEQ)   # 2325 + 105
+BWD_ELEMS = (NZ * NZ + NINEQ * NZ + NEQ * NZ + NZ + 2 * NINEQ + NEQ + NZ) + \
+            (NZ * NZ + NZ + NINEQ * NZ + NINEQ + NEQ * NZ + NEQ)                             # 2385 + 2325
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6      # public MI355X spec (vector = matrix fp64); not in the guide
+
+
+def family_R(seed, B, nz, nineq, neq):
+    g = torch.Generator().manual_seed(seed)
+    L = torch.randn(B, nz, nz, generator=g, dtype=torch.float64)
+    Q = L @ L.transpose(1, 2) + 1e-3 * torch.eye(nz, dtype=torch.float64)
+    G = torch.randn(B, nineq, nz, generator=g, dtype=torch.float64)
+    z0 = torch.randn(B, nz, generator=g, dtype=torch.float64)
+    s0 = torch.rand(B, nineq, generator=g, dtype=torch.float64)
+    A = torch.randn(B, neq, nz, generator=g, dtype=torch.float64)
+    p = torch.randn(B, nz, generator=g, dtype=torch.float64)
+    h = (G @ z0.unsqueeze(-1)).squeeze(-1) + s0
+    b = (A @ z0.unsqueeze(-1)).squeeze(-1)
+    return Q, p, G, h, A, b
+
+
+class HotPath:
+    """Pre-allocated buffers + the two C-ABI calls of one step."""
+
+    def __init__(self, dev, host_inputs):
+        from diff_qp_mpc_amd import _lib
+        self._lib = _lib
+        self.lib = _lib.load()
+        self.dev = dev
+        B = host_inputs[0].shape[0]
+        self.B = B
+        self.Q, self.p, self.G, self.h, self.A, self.b = [t.to(dev).contiguous() for t in host_inputs]
+        kw = dict(dtype=torch.float64, device=dev)
+        self.zhat = torch.empty(B, NZ, **kw); self.lam = torch.empty(B, NINEQ, **kw)
+        self.nu = torch.empty(B, NEQ, **kw); self.slack = torch.empty(B, NINEQ, **kw)
+        self.info = torch.empty(B, 2, dtype=torch.int32, device=dev)
+        self.resid = torch.empty(B, **kw)
+        self.ct = torch.ones(B, NZ, **kw)
+        self.dQ = torch.empty(B, NZ, NZ, **kw); self.dp = torch.empty(B, NZ, **kw)
+        self.dG = torch.empty(B, NINEQ, NZ, **kw); self.dh = torch.empty(B, NINEQ, **kw)
+        self.dA = torch.empty(B, NEQ, NZ, **kw); self.db = torch.empty(B, NEQ, **kw)
+        self.dims = _lib.dqp_dims(B, NZ, NINEQ, NEQ, NZ * NZ, NZ, NINEQ * NZ, NINEQ, NEQ * NZ, NEQ)
+        self.opts = _lib.dqp_opts(1e-12, 20, 3, 0, 0)
+        self.stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())
+        self.fargs = [P(t) for t in (self.Q, self.p, self.G, self.h, self.A, self.b, self.zhat,
+                                     self.lam, self.nu, self.slack, self.info, self.resid)]
+        self.bargs = [P(t) for t in (self.Q, self.G, self.A, self.zhat, self.lam, self.nu,
+                                     self.slack, self.ct, self.dQ, self.dp, self.dG, self.dh,
+                                     self.dA, self.db)]
+        self.null = ctypes.c_void_p(0)
+
+    def forward(self):
+        rc = self.lib.dqp_qp_forward(ctypes.byref(self.dims), ctypes.byref(self.opts), *self.fargs,
+                                     self.null, self.stream)
+        if rc:
+            raise RuntimeError("dqp_qp_forward rc=%d" % rc)
+
+    def backward(self):
+        rc = self.lib.dqp_qp_backward(ctypes.byref(self.dims), ctypes.byref(self.opts), *self.bargs,
+                                      self.null, self.null, self.stream)
+        if rc:
+            raise RuntimeError("dqp_qp_backward rc=%d" % rc)
+
+
+def cpu_baseline(host_inputs, reps=3):
+    """The oracle (a C port of the reference's algorithm, OpenMP over the batch) on this host."""
+    from oracle import oracle
+    Q, p, G, h, A, b = [t.numpy() for t in host_inputs]
+    B = Q.shape[0]
+    nthreads = oracle.max_threads()
+    ct = np.ones((B, NZ))
+    ts = []
+    for r in range(reps + 1):
+        t0 = time.perf_counter()
+        o = oracle.qp_forward(Q, p, G, h, A, b, nthreads=nthreads)
+        oracle.qp_backward(Q, G, A, o["zhat"], o["lam"], o["nu"], o["slack"], ct, nthreads=nthreads)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts[1:]))
+    return {"value": B / t, "unit": "QPs/sec", "cores": nthreads, "kind": "port",
+            "sample": "same workload, %d QPs fwd+bwd, median of %d reps after 1 warm-up; "
+                      "batch-coupled PDIPM ran %d iterations" % (B, reps, o["iters"])}, o
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    host_inputs = family_R(rank, B_PER_GPU, NZ, NINEQ, NEQ)
+    hp = HotPath(dev, host_inputs)
+    gathered = torch.empty(world * B_PER_GPU, NZ, dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        hp.forward()
+        if world > 1:   # north_star: a single RCCL gather of the solved batch
+            dist.all_gather_into_tensor(gathered, hp.zhat)
+        hp.backward()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]
+    bev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+           for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        fev[k][0].record(); hp.forward(); fev[k][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, hp.zhat)
+        bev[k][0].record(); hp.backward(); bev[k][1].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fwd_ms = float(np.mean([a.elapsed_time(b) for a, b in fev]))
+    bwd_ms = float(np.mean([a.elapsed_time(b) for a, b in bev]))
+    iters = hp.info[:, 1].float()
+    status_bad = int((hp.info[:, 0] != 0).sum())
+
+    if rank == 0:
+        qps = world * B_PER_GPU * args.steps / elapsed
+        fwd_bytes = FWD_ELEMS * 8 * B_PER_GPU
+        bwd_bytes = BWD_ELEMS * 8 * B_PER_GPU
+        fwd_gbs = fwd_bytes / (fwd_ms * 1e-3) / 1e9
+        out = {
+            "metric": "QPs/sec (fwd+bwd), batch=4096 n=3 m=3 T=5",
+            "value": qps, "unit": "QPs/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "random dense QP family R (SURVEY §8d), configs[0] shape at "
+                                   "BASELINE metric batch: B=4096/GPU nz=30 nineq=30 neq=15",
+                       "global_batch": world * B_PER_GPU, "n_state": 3, "n_ctrl": 3, "T": 5,
+                       "parallelism": "batch-shard x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "qp_forward_kernel",
+                         "achieved": fwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": fwd_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": fwd_ms, "algorithmic_bytes_per_launch": fwd_bytes},
+            "kernels": {"qp_forward_kernel_ms": fwd_ms, "qp_backward_kernel_ms": bwd_ms,
+                        "backward_GBps": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
+                        "pdipm_iters_mean": float(iters.mean()), "pdipm_iters_max": float(iters.max()),
+                        "status_nonzero": status_bad},
+        }
+        if not args.no_cpu_baseline:
+            cb, o = cpu_baseline(host_inputs)
+            out["cpu_baseline"] = cb
+            err = float(np.abs(hp.zhat.cpu().numpy() - o["zhat"]).max())
+            out["max_abs_err_vs_cpu_zhat"] = err
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

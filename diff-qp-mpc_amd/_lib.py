@@ -1,0 +1,75 @@
+"""ctypes binding of the C ABI in include/dqp.h (csrc/libdqp_hip.so).
+
+The library is loaded lazily on first use and there is deliberately no fallback: a missing
+or unloadable library raises RuntimeError naming the build command.
+"""
+import ctypes
+import os
+
+from . import _build
+
+_dp = ctypes.c_void_p
+
+
+class dqp_dims(ctypes.Structure):
+    _fields_ = [("nbatch", ctypes.c_int32), ("nz", ctypes.c_int32), ("nineq", ctypes.c_int32),
+                ("neq", ctypes.c_int32),
+                ("stride_Q", ctypes.c_int64), ("stride_p", ctypes.c_int64),
+                ("stride_G", ctypes.c_int64), ("stride_h", ctypes.c_int64),
+                ("stride_A", ctypes.c_int64), ("stride_b", ctypes.c_int64)]
+
+
+class dqp_opts(ctypes.Structure):
+    _fields_ = [("eps", ctypes.c_double), ("max_iter", ctypes.c_int32),
+                ("not_improved_lim", ctypes.c_int32), ("flags", ctypes.c_uint32),
+                ("reserved", ctypes.c_int32)]
+
+
+DQP_OK = 0
+DQP_FLAG_DENSE_BACKWARD = 1
+DQP_STATUS_Q_NOT_PD = 1
+DQP_STATUS_A_RANK_DEF = 2
+DQP_MAX_DIM = 64
+
+# every symbol include/dqp.h declares
+SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes",
+           "dqp_qp_forward", "dqp_qp_backward")
+
+_lib = None
+
+
+def path():
+    return _build.SO
+
+
+def load():
+    """Returns the ctypes CDLL; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    so = path()
+    if not os.path.exists(so):
+        raise RuntimeError(
+            "diff_qp_mpc_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % so)
+    try:
+        lib = ctypes.CDLL(so)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError("diff_qp_mpc_amd: cannot load %s: %s" % (so, e))
+    lib.dqp_version.restype = ctypes.c_int
+    lib.dqp_error_string.restype = ctypes.c_char_p
+    lib.dqp_error_string.argtypes = [ctypes.c_int]
+    lib.dqp_workspace_bytes.restype = ctypes.c_size_t
+    lib.dqp_workspace_bytes.argtypes = [ctypes.POINTER(dqp_dims)]
+    lib.dqp_qp_forward.restype = ctypes.c_int
+    lib.dqp_qp_forward.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 14
+    lib.dqp_qp_backward.restype = ctypes.c_int
+    lib.dqp_qp_backward.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 17
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != DQP_OK:
+        msg = load().dqp_error_string(rc).decode()
+        raise RuntimeError("diff_qp_mpc_amd: %s failed: %s (code %d)" % (what, msg, rc))

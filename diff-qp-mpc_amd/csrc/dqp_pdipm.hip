@@ -1,0 +1,620 @@
+// dqp_pdipm.hip -- fused PDIPM forward + KKT backward for small dense QPs on gfx950.
+//
+// One QP per 64-lane wavefront (one single-wave workgroup per QP).  Every matrix the
+// interior-point iteration touches lives in LDS for the whole solve; every vector lives in
+// registers, element i on lane i; the only HBM traffic is the coalesced read of
+// (Q,p,G,h,A,b) and the write of (zhat,lam,nu,slack).  There is no host synchronisation and
+// no per-iteration kernel launch (the reference does ~60 launches + 2 host syncs per
+// iteration: qpth/solvers/pdipm/batch.py:91-204).
+//
+// Math.  The reference eliminates the KKT system with LU(Q) and a block LU of
+//   S = [A Q^-1 A^T, A Q^-1 G^T; G Q^-1 A^T, G Q^-1 G^T + D^-1]      (batch.py:351-428).
+// Newton's method is affine invariant, so we run the SAME iteration in the coordinates
+//   xh = Lq^T x  (Q = Lq Lq^T),  yt = L1^T y  (A Q^-1 A^T = L1 L1^T)
+// where Q becomes I and A becomes At = L1^-1 A Lq^-T with orthonormal rows:
+//   Gh = G Lq^-T,  R = Gh (I - At^T At) Gh^T  (== the reference's Schur complement R),
+//   T  = R + diag(s/z)  factored per iteration as L D L^T (the symmetric form of the
+//        unpivoted LU the reference uses on GPUs, batch.py:8-19).
+// A KKT solve is then 4 small mat-vecs with Gh/At plus one LDL^T solve; s, z (lam) and the
+// step-length rule are untouched by the change of variables, residual norms are mapped back
+// (||rx|| = ||Lq rxh||, ||ry|| = ||L1 ryt||) so best-iterate selection follows batch.py:98-140.
+//
+// Reference functions covered: a2 pre_factor_kkt, a3 forward, a4 factor_kkt,
+// a5 solve_kkt, a6 get_step, a8 QPFunctionFn.backward, a9/a10 DenseQPFunction (same Newton
+// systems; flag selects its un-clamped backward).
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/dqp.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+
+struct KParams {
+    const double *Q, *p, *G, *h, *A, *b;
+    long long sQ, sp, sG, sh, sA, sb;
+    // forward outputs
+    double *zhat, *lam, *nu, *slack, *best_resid;
+    // backward inputs / outputs
+    const double *zin, *lamin, *nuin, *slackin, *gin;
+    double *dQ, *dp, *dG, *dh, *dA, *db;
+    int32_t *info;
+    int B, N, M, E;
+    int ldz, ldm, lde, ldt;
+    double eps;
+    int maxIter, notImprovedLim;
+    unsigned flags;
+};
+
+#define WSYNC() __syncthreads()
+
+__device__ __forceinline__ double bcast(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ double wave_min(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
+    return v;
+}
+
+// y_i = sum_{j<n} M[i][j] x_j for lanes i < m (0 elsewhere).  x: element j on lane j.
+__device__ __forceinline__ double matvec(const double *Mx, int ld, int m, int n, double x, int lane)
+{
+    const double *row = Mx + (lane < m ? lane : 0) * ld;
+    double a0 = 0.0, a1 = 0.0;
+    int j = 0;
+    for (; j + 1 < n; j += 2) {
+        a0 = fma(row[j], bcast(x, j), a0);
+        a1 = fma(row[j + 1], bcast(x, j + 1), a1);
+    }
+    if (j < n) a0 = fma(row[j], bcast(x, j), a0);
+    return lane < m ? a0 + a1 : 0.0;
+}
+
+// y_j = sum_{i<m} M[i][j] x_i for lanes j < n (0 elsewhere).  x: element i on lane i.
+__device__ __forceinline__ double matvecT(const double *Mx, int ld, int m, int n, double x, int lane)
+{
+    const double *col = Mx + (lane < n ? lane : 0);
+    double a0 = 0.0, a1 = 0.0;
+    int i = 0;
+    for (; i + 1 < m; i += 2) {
+        a0 = fma(col[i * ld], bcast(x, i), a0);
+        a1 = fma(col[(i + 1) * ld], bcast(x, i + 1), a1);
+    }
+    if (i < m) a0 = fma(col[i * ld], bcast(x, i), a0);
+    return lane < n ? a0 + a1 : 0.0;
+}
+
+// y_i = sum_{j<=i} L[i][j] x_j (lower-triangular mat-vec; the strict upper part is not read)
+__device__ __forceinline__ double trimatvec(const double *L, int ld, int n, double x, int lane)
+{
+    const double *row = L + (lane < n ? lane : 0) * ld;
+    double a = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double xj = bcast(x, j);
+        if (j <= lane && lane < n) a = fma(row[j], xj, a);
+    }
+    return a;
+}
+
+// In-place lower Cholesky of the n x n matrix in LDS; rd = 1/L[i][i] on lane i.
+__device__ bool chol_factor(double *L, int ld, int n, int lane, double &rd)
+{
+    bool ok = true;
+    rd = 0.0;
+    for (int k = 0; k < n; ++k) {
+        WSYNC();
+        double dk = L[k * ld + k];
+        if (!(dk > 0.0)) { ok = false; dk = 1.0; }
+        const double sq = sqrt(dk), r = 1.0 / sq;
+        const bool act = lane > k && lane < n;
+        double c = 0.0;
+        if (lane == k) { rd = r; L[k * ld + k] = sq; }
+        if (act) { c = L[lane * ld + k] * r; L[lane * ld + k] = c; }
+        for (int i = k + 1; i < n; ++i) {
+            const double ci = bcast(c, i);
+            if (act && lane <= i) L[i * ld + lane] = fma(-ci, c, L[i * ld + lane]);
+        }
+    }
+    WSYNC();
+    return ok;
+}
+
+// In-place L D L^T of the symmetric n x n matrix in LDS (unit L in the strict lower part).
+// Returns 1/D[i] on lane i.
+__device__ double ldl_factor(double *T, int ld, int n, int lane)
+{
+    double rdiag = 0.0;
+    for (int k = 0; k < n; ++k) {
+        WSYNC();
+        const double r = 1.0 / T[k * ld + k];
+        const bool act = lane > k && lane < n;
+        double c = 0.0, l = 0.0;
+        if (lane == k) rdiag = r;
+        if (act) { c = T[lane * ld + k]; l = c * r; T[lane * ld + k] = l; }
+        for (int i = k + 1; i < n; ++i) {
+            const double li = bcast(l, i);
+            if (act && lane <= i) T[i * ld + lane] = fma(-li, c, T[i * ld + lane]);
+        }
+    }
+    WSYNC();
+    return rdiag;
+}
+
+__device__ __forceinline__ double ldl_solve(const double *T, int ld, int n, double b, double rdiag, int lane)
+{
+    for (int k = 0; k < n - 1; ++k) {
+        const double bk = bcast(b, k);
+        if (lane > k && lane < n) b = fma(-T[lane * ld + k], bk, b);
+    }
+    b *= rdiag;
+    for (int k = n - 1; k > 0; --k) {
+        const double bk = bcast(b, k);
+        if (lane < k) b = fma(-T[k * ld + lane], bk, b);
+    }
+    return b;
+}
+
+// L y = b (L lower, non-unit; rd = reciprocal diagonal, element i on lane i)
+__device__ __forceinline__ double trsv_L(const double *L, int ld, int n, double b, double rd, int lane)
+{
+    for (int k = 0; k < n; ++k) {
+        const double yk = bcast(b * rd, k);
+        if (lane == k) b = yk;
+        else if (lane > k && lane < n) b = fma(-L[lane * ld + k], yk, b);
+    }
+    return b;
+}
+
+// L^T x = b
+__device__ __forceinline__ double trsv_LT(const double *L, int ld, int n, double b, double rd, int lane)
+{
+    for (int k = n - 1; k >= 0; --k) {
+        const double xk = bcast(b * rd, k);
+        if (lane == k) b = xk;
+        else if (lane < k) b = fma(-L[k * ld + lane], xk, b);
+    }
+    return b;
+}
+
+struct Lds {
+    double *Lq, *Gh, *At, *L1, *R, *T, *W;
+};
+
+__device__ __forceinline__ Lds carve(double *sm, const KParams &P)
+{
+    Lds s;
+    s.Lq = sm;
+    s.Gh = s.Lq + P.N * P.ldz;
+    s.At = s.Gh + P.M * P.ldz;
+    s.L1 = s.At + P.E * P.ldz;
+    s.R = s.L1 + P.E * P.lde;
+    s.T = s.R + P.M * P.ldm;
+    s.W = s.T + P.M * P.ldt;
+    return s;
+}
+
+// One-time factorisations (reference: pre_factor_kkt, batch.py:377-428).
+// On return: Lq (chol Q), Gh = G Lq^-T, At = L1^-1 A Lq^-T, L1 = chol(A Q^-1 A^T),
+// R = Gh (I - At^T At) Gh^T; rdq / rd1 = reciprocal diagonals of Lq / L1 on lane i.
+__device__ int qp_setup(const KParams &P, const Lds &S, int qp, int lane, double &rdq, double &rd1)
+{
+    const int N = P.N, M = P.M, E = P.E, ldz = P.ldz, ldm = P.ldm, lde = P.lde, ldt = P.ldt;
+    const double *Q = P.Q + (long long)qp * P.sQ;
+    const double *G = P.G + (long long)qp * P.sG;
+    const double *A = E ? P.A + (long long)qp * P.sA : nullptr;
+    int status = DQP_STATUS_OK;
+
+    // coalesced row loads into padded LDS rows
+    for (int i = 0; i < N; ++i)
+        if (lane < N) S.Lq[i * ldz + lane] = Q[i * N + lane];
+    for (int i = 0; i < M; ++i)
+        if (lane < N) S.Gh[i * ldz + lane] = G[i * N + lane];
+    for (int i = 0; i < E; ++i)
+        if (lane < N) S.At[i * ldz + lane] = A[i * N + lane];
+
+    if (!chol_factor(S.Lq, ldz, N, lane, rdq)) status = DQP_STATUS_Q_NOT_PD;
+
+    // rows of G and A -> solve Lq r = row  (lanes = right-hand sides)
+    for (int base = 0; base < M + E; base += WAVE) {
+        const int r = base + lane;
+        if (r < M + E) {
+            double *row = r < M ? S.Gh + r * ldz : S.At + (r - M) * ldz;
+            for (int k = 0; k < N; ++k) {
+                double v = row[k];
+                const double *Lk = S.Lq + k * ldz;
+                for (int j = 0; j < k; ++j) v = fma(-Lk[j], row[j], v);
+                row[k] = v / Lk[k];
+            }
+        }
+    }
+    WSYNC();
+
+    rd1 = 0.0;
+    if (E > 0) {
+        // S11 = Ah Ah^T
+        for (int base = 0; base < E * E; base += WAVE) {
+            const int idx = base + lane;
+            if (idx < E * E) {
+                const int i = idx / E, j = idx - i * E;
+                const double *ri = S.At + i * ldz, *rj = S.At + j * ldz;
+                double a = 0.0;
+                for (int k = 0; k < N; ++k) a = fma(ri[k], rj[k], a);
+                S.L1[i * lde + j] = a;
+            }
+        }
+        if (!chol_factor(S.L1, lde, E, lane, rd1) && status == DQP_STATUS_OK)
+            status = DQP_STATUS_A_RANK_DEF;
+        // At = L1^-1 Ah  (lanes = columns)
+        if (lane < N) {
+            for (int i = 0; i < E; ++i) {
+                double v = S.At[i * ldz + lane];
+                const double *Li = S.L1 + i * lde;
+                for (int j = 0; j < i; ++j) v = fma(-Li[j], S.At[j * ldz + lane], v);
+                S.At[i * ldz + lane] = v / Li[i];
+            }
+        }
+        WSYNC();
+        // W = Gh At^T (M x E)
+        for (int base = 0; base < M * E; base += WAVE) {
+            const int idx = base + lane;
+            if (idx < M * E) {
+                const int i = idx / E, e = idx - i * E;
+                const double *gi = S.Gh + i * ldz, *ae = S.At + e * ldz;
+                double a = 0.0;
+                for (int k = 0; k < N; ++k) a = fma(gi[k], ae[k], a);
+                S.W[i * lde + e] = a;
+            }
+        }
+        WSYNC();
+    }
+    // Gbar = Gh - W At  (staged in the T buffer, row stride ldt), then R = Gbar Gbar^T
+    if (lane < N) {
+        for (int i = 0; i < M; ++i) {
+            double v = S.Gh[i * ldz + lane];
+            for (int e = 0; e < E; ++e) v = fma(-S.W[i * lde + e], S.At[e * ldz + lane], v);
+            S.T[i * ldt + lane] = v;
+        }
+    }
+    WSYNC();
+    for (int base = 0; base < M * M; base += WAVE) {
+        const int idx = base + lane;
+        if (idx < M * M) {
+            const int i = idx / M, j = idx - i * M;
+            const double *gi = S.T + i * ldt, *gj = S.T + j * ldt;
+            double a = 0.0;
+            for (int k = 0; k < N; ++k) a = fma(gi[k], gj[k], a);
+            S.R[i * ldm + j] = a;
+        }
+    }
+    WSYNC();
+    return status;
+}
+
+// T = R + diag(dinv), then L D L^T.  dinv: element i on lane i.  Returns 1/D on lane i.
+__device__ __forceinline__ double factor_T(const KParams &P, const Lds &S, double dinv, int lane)
+{
+    const int M = P.M, ldm = P.ldm, ldt = P.ldt;
+    WSYNC();
+    for (int i = 0; i < M; ++i) {
+        const double di = bcast(dinv, i);
+        if (lane < M) S.T[i * ldt + lane] = S.R[i * ldm + lane] + (lane == i ? di : 0.0);
+    }
+    return ldl_factor(S.T, ldt, M, lane);
+}
+
+// z-part of solve_kkt in hat coordinates: returns wz = dz.
+//   rxh (lane<N), rsd = rs/d (lane<M), rz (lane<M), ryt (lane<E)
+__device__ __forceinline__ double kkt_wz(const KParams &P, const Lds &S, double rdT, double rxh,
+                                         double rsd, double rz, double ryt, int lane)
+{
+    const int N = P.N, M = P.M, E = P.E;
+    double u = rxh;
+    if (E > 0) {
+        const double t = matvec(S.At, P.ldz, E, N, rxh, lane) - ryt;
+        u = rxh - matvecT(S.At, P.ldz, E, N, t, lane);
+    }
+    const double g = rz - rsd - matvec(S.Gh, P.ldz, M, N, u, lane);
+    return ldl_solve(S.T, P.ldt, M, g, rdT, lane);
+}
+
+// x/y-part of solve_kkt for (the sum of) wz: dxh = -q + At^T(At q - ryt), dyt = -(At q - ryt)
+__device__ __forceinline__ void kkt_xy(const KParams &P, const Lds &S, double rxh, double ryt,
+                                       double wz, int lane, double &dxh, double &dyt)
+{
+    const int N = P.N, M = P.M, E = P.E;
+    const double q = rxh + matvecT(S.Gh, P.ldz, M, N, wz, lane);
+    dxh = -q;
+    dyt = 0.0;
+    if (E > 0) {
+        const double e = matvec(S.At, P.ldz, E, N, q, lane) - ryt;
+        dxh += matvecT(S.At, P.ldz, E, N, e, lane);
+        dyt = -e;
+    }
+}
+
+__device__ __forceinline__ double step_ratio(double v, double dv, bool active)
+{
+    // batch.py:211-214: entries with dv > 0 never bind after the min(., 1)
+    return (active && dv < 0.0) ? -v / dv : INFINITY;
+}
+
+__global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x, qp = blockIdx.x;
+    const int N = P.N, M = P.M, E = P.E;
+    const Lds S = carve(sm, P);
+
+    double rdq, rd1;
+    const int status = qp_setup(P, S, qp, lane, rdq, rd1);
+    const bool inN = lane < N, inM = lane < M, inE = lane < E;
+
+    double ph = inN ? P.p[(long long)qp * P.sp + lane] : 0.0;
+    const double hh = inM ? P.h[(long long)qp * P.sh + lane] : 0.0;
+    double bt = inE ? P.b[(long long)qp * P.sb + lane] : 0.0;
+    ph = trsv_L(S.Lq, P.ldz, N, ph, rdq, lane);
+    if (E > 0) bt = trsv_L(S.L1, P.lde, E, bt, rd1, lane);
+
+    // initial point: d = 1, solve_kkt(p, 0, -h, -b)                     batch.py:60-74
+    double rdT = factor_T(P, S, inM ? 1.0 : 0.0, lane);
+    double xh, s, z, yt;
+    {
+        const double wz = kkt_wz(P, S, rdT, ph, 0.0, -hh, -bt, lane);
+        kkt_xy(P, S, ph, -bt, wz, lane, xh, yt);
+        z = wz;
+        s = -wz;
+    }
+    {   // make s, z >= 1                                                  batch.py:76-86
+        const double ms = wave_min(inM ? s : INFINITY), mz = wave_min(inM ? z : INFINITY);
+        if (ms < 0.0 && inM) s -= ms - 1.0;
+        if (mz < 0.0 && inM) z -= mz - 1.0;
+    }
+
+    double bxh = xh, bs = s, bz = z, byt = yt, best = INFINITY;
+    bool have_best = false;
+    int nNotImproved = 0, iters = 0;
+
+    for (int it = 0; it < P.maxIter; ++it) {
+        // residuals in hat coordinates                                   batch.py:93-108
+        double rxh = xh + ph + matvecT(S.Gh, P.ldz, M, N, z, lane);
+        double ryt = 0.0;
+        if (E > 0) {
+            rxh += matvecT(S.At, P.ldz, E, N, yt, lane);
+            ryt = matvec(S.At, P.ldz, E, N, xh, lane) - bt;
+        }
+        const double gx = matvec(S.Gh, P.ldz, M, N, xh, lane);
+        const double rz = inM ? gx + s - hh : 0.0;
+        const double rx = trimatvec(S.Lq, P.ldz, N, rxh, lane);       // rx = Lq rxh
+        double ry = 0.0;
+        if (E > 0) ry = trimatvec(S.L1, P.lde, E, ryt, lane);
+        const double sz = wave_sum(inM ? s * z : 0.0);
+        const double mu = fabs(sz / M);
+        const double resid = sqrt(wave_sum(rz * rz)) + sqrt(wave_sum(ry * ry)) +
+                             sqrt(wave_sum(rx * rx)) + M * mu;
+        iters = it + 1;
+        // best-iterate tracking                                          batch.py:119-140
+        if (!have_best || resid < best) {
+            nNotImproved = 0;
+            have_best = true;
+            best = resid; bxh = xh; bs = s; bz = z; byt = yt;
+        } else {
+            nNotImproved += 1;
+        }
+        if (nNotImproved == P.notImprovedLim || best < P.eps || mu > 1e32) break;
+
+        const double dinv = inM ? s / z : 0.0;                          // 1/d, d = z/s
+        rdT = factor_T(P, S, dinv, lane);
+
+        // affine direction (rs = z  =>  rs/d = s)                        batch.py:151
+        const double dz_a = kkt_wz(P, S, rdT, rxh, s, rz, ryt, lane);
+        const double ds_a = inM ? (-z - dz_a) * dinv : 0.0;
+        double alpha = fmin(wave_min(fmin(step_ratio(z, dz_a, inM), step_ratio(s, ds_a, inM))), 1.0);
+        const double t3 = wave_sum(inM ? (s + alpha * ds_a) * (z + alpha * dz_a) : 0.0);
+        double sig = t3 / sz;
+        sig = sig * sig * sig;
+        // corrector: rx = rz = ry = 0, rs = (-mu sig + ds_a dz_a)/s       batch.py:171-181
+        const double rs_c = inM ? (-mu * sig + ds_a * dz_a) / s : 0.0;
+        const double dz_c = ldl_solve(S.T, P.ldt, M, -rs_c * dinv, rdT, lane);
+        const double ds_c = inM ? (-rs_c - dz_c) * dinv : 0.0;
+        const double dz = dz_a + dz_c, ds = ds_a + ds_c;
+        double dxh, dyt;
+        kkt_xy(P, S, rxh, ryt, dz, lane, dxh, dyt);
+
+        alpha = fmin(0.999 * wave_min(fmin(step_ratio(z, dz, inM), step_ratio(s, ds, inM))), 1.0);
+        xh += alpha * dxh;
+        s += alpha * ds;
+        z += alpha * dz;
+        yt += alpha * dyt;
+    }
+
+    // back to the caller's coordinates: x = Lq^-T xh, y = L1^-T yt
+    const double x = trsv_LT(S.Lq, P.ldz, N, bxh, rdq, lane);
+    if (inN) P.zhat[(long long)qp * N + lane] = x;
+    if (inM) {
+        P.lam[(long long)qp * M + lane] = bz;
+        P.slack[(long long)qp * M + lane] = bs;
+    }
+    if (E > 0) {
+        const double y = trsv_LT(S.L1, P.lde, E, byt, rd1, lane);
+        if (inE) P.nu[(long long)qp * E + lane] = y;
+    }
+    if (lane == 0) {
+        if (P.info) { P.info[2 * qp] = status; P.info[2 * qp + 1] = iters; }
+        if (P.best_resid) P.best_resid[qp] = best;
+    }
+}
+
+// QPFunctionFn.backward (qp.py:128-183) / DenseQPFunction Solver.backward (qp.py:239-270)
+__global__ __launch_bounds__(WAVE) void qp_backward_kernel(KParams P)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x, qp = blockIdx.x;
+    const int N = P.N, M = P.M, E = P.E;
+    const Lds S = carve(sm, P);
+
+    double rdq, rd1;
+    const int status = qp_setup(P, S, qp, lane, rdq, rd1);
+    const bool inN = lane < N, inM = lane < M, inE = lane < E;
+
+    const double zh = inN ? P.zin[(long long)qp * N + lane] : 0.0;
+    const double lam = inM ? P.lamin[(long long)qp * M + lane] : 0.0;
+    const double slk = inM ? P.slackin[(long long)qp * M + lane] : 1.0;
+    const double nu = inE ? P.nuin[(long long)qp * E + lane] : 0.0;
+    double g = inN ? P.gin[(long long)qp * N + lane] : 0.0;
+
+    double dinv;
+    if (P.flags & DQP_FLAG_DENSE_BACKWARD) dinv = inM ? slk / lam : 0.0;
+    else dinv = inM ? fmax(slk, 1e-8) / fmax(lam, 1e-8) : 0.0;       // qp.py:149
+    const double rdT = factor_T(P, S, dinv, lane);
+
+    // solve_kkt(rx = dl_dzhat, 0, 0, 0)
+    const double rxh = trsv_L(S.Lq, P.ldz, N, g, rdq, lane);
+    const double dlam = kkt_wz(P, S, rdT, rxh, 0.0, 0.0, 0.0, lane);
+    double dxh, dyt;
+    kkt_xy(P, S, rxh, 0.0, dlam, lane, dxh, dyt);
+    const double dx = trsv_LT(S.Lq, P.ldz, N, dxh, rdq, lane);
+    double dnu = 0.0;
+    if (E > 0) dnu = trsv_LT(S.L1, P.lde, E, dyt, rd1, lane);
+
+    // gradients; lanes run along the nz (contiguous) axis -> coalesced row stores
+    if (P.dp && inN) P.dp[(long long)qp * N + lane] = dx;
+    if (P.dh && inM) P.dh[(long long)qp * M + lane] = -dlam;
+    if (P.db && inE) P.db[(long long)qp * E + lane] = -dnu;
+    if (P.dQ) {
+        double *o = P.dQ + (long long)qp * N * N;
+        for (int i = 0; i < N; ++i) {
+            const double dxi = bcast(dx, i), zi = bcast(zh, i);
+            if (inN) o[i * N + lane] = 0.5 * (dxi * zh + zi * dx);
+        }
+    }
+    if (P.dG) {
+        double *o = P.dG + (long long)qp * M * N;
+        for (int i = 0; i < M; ++i) {
+            const double dli = bcast(dlam, i), li = bcast(lam, i);
+            if (inN) o[i * N + lane] = dli * zh + li * dx;
+        }
+    }
+    if (P.dA && E > 0) {
+        double *o = P.dA + (long long)qp * E * N;
+        for (int i = 0; i < E; ++i) {
+            const double dni = bcast(dnu, i), ni = bcast(nu, i);
+            if (inN) o[i * N + lane] = dni * zh + ni * dx;
+        }
+    }
+    if (lane == 0 && P.info) { P.info[2 * qp] = status; P.info[2 * qp + 1] = 0; }
+}
+
+int fill_params(const dqp_dims *d, const dqp_opts *o, KParams &P, size_t &lds_bytes)
+{
+    if (!d) return DQP_ERR_BAD_ARG;
+    if (d->nbatch < 0 || d->nz <= 0 || d->nineq <= 0 || d->neq < 0) return DQP_ERR_BAD_ARG;
+    if (d->nz > DQP_MAX_DIM || d->nineq > DQP_MAX_DIM || d->neq > DQP_MAX_DIM) return DQP_ERR_TOO_LARGE;
+    P.B = d->nbatch; P.N = d->nz; P.M = d->nineq; P.E = d->neq;
+    P.ldz = d->nz | 1; P.ldm = d->nineq | 1; P.lde = d->neq | 1;
+    P.ldt = P.ldz > P.ldm ? P.ldz : P.ldm;
+    P.sQ = d->stride_Q; P.sp = d->stride_p; P.sG = d->stride_G;
+    P.sh = d->stride_h; P.sA = d->stride_A; P.sb = d->stride_b;
+    P.eps = o ? o->eps : 1e-12;
+    P.maxIter = o ? o->max_iter : 20;
+    P.notImprovedLim = o ? o->not_improved_lim : 3;
+    P.flags = o ? o->flags : 0u;
+    size_t n = (size_t)P.N * P.ldz + (size_t)P.M * P.ldz + (size_t)P.E * P.ldz +
+               (size_t)P.E * P.lde + (size_t)P.M * P.ldm + (size_t)P.M * P.ldt +
+               (size_t)P.M * P.lde;
+    lds_bytes = n * sizeof(double);
+    if (lds_bytes > 160 * 1024) return DQP_ERR_TOO_LARGE;
+    return DQP_OK;
+}
+
+template <typename K>
+int launch(K kernel, const KParams &P, size_t lds_bytes, void *stream)
+{
+    if (P.B == 0) return DQP_OK;
+    if (lds_bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes) != hipSuccess)
+            return DQP_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(kernel, dim3(P.B), dim3(WAVE), lds_bytes, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) int dqp_version(void) { return DQP_VERSION; }
+
+__attribute__((visibility("default"))) const char *dqp_error_string(int code)
+{
+    switch (code) {
+    case DQP_OK: return "ok";
+    case DQP_ERR_BAD_ARG: return "bad argument";
+    case DQP_ERR_TOO_LARGE: return "problem too large for the fused one-wavefront kernels";
+    case DQP_ERR_LAUNCH: return "HIP kernel launch failed";
+    case DQP_ERR_NO_DEVICE: return "no HIP device";
+    default: return "unknown error";
+    }
+}
+
+__attribute__((visibility("default"))) size_t dqp_workspace_bytes(const dqp_dims *) { return 0; }
+
+__attribute__((visibility("default"))) int
+dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, const double *p,
+               const double *G, const double *h, const double *A, const double *b, double *zhat,
+               double *lam, double *nu, double *slack, int32_t *info, double *best_resid,
+               void * /*workspace*/, void *stream)
+{
+    KParams P = {};
+    size_t lds = 0;
+    int rc = fill_params(dims, opts, P, lds);
+    if (rc != DQP_OK) return rc;
+    if (P.B == 0) return DQP_OK;
+    if (!Q || !p || !G || !h || !zhat || !lam || !slack) return DQP_ERR_BAD_ARG;
+    if (P.E > 0 && (!A || !b || !nu)) return DQP_ERR_BAD_ARG;
+    P.Q = Q; P.p = p; P.G = G; P.h = h; P.A = A; P.b = b;
+    P.zhat = zhat; P.lam = lam; P.nu = nu; P.slack = slack;
+    P.info = info; P.best_resid = best_resid;
+    return launch(qp_forward_kernel, P, lds, stream);
+}
+
+__attribute__((visibility("default"))) int
+dqp_qp_backward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, const double *G,
+                const double *A, const double *zhat, const double *lam, const double *nu,
+                const double *slack, const double *dl_dzhat, double *dQ, double *dp, double *dG,
+                double *dh, double *dA, double *db, int32_t *info, void * /*workspace*/,
+                void *stream)
+{
+    KParams P = {};
+    size_t lds = 0;
+    int rc = fill_params(dims, opts, P, lds);
+    if (rc != DQP_OK) return rc;
+    if (P.B == 0) return DQP_OK;
+    if (!Q || !G || !zhat || !lam || !slack || !dl_dzhat) return DQP_ERR_BAD_ARG;
+    if (P.E > 0 && (!A || !nu)) return DQP_ERR_BAD_ARG;
+    P.Q = Q; P.G = G; P.A = A;
+    P.zin = zhat; P.lamin = lam; P.nuin = nu; P.slackin = slack; P.gin = dl_dzhat;
+    P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db;
+    P.info = info;
+    return launch(qp_backward_kernel, P, lds, stream);
+}
+
+}  // extern "C"

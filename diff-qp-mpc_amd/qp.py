@@ -1,0 +1,223 @@
+"""QPFunction / DenseQPFunction with the reference's signatures (qpth/qp.py:19-183, 187-271),
+computed by the fused HIP kernels behind the C ABI (include/dqp.h).
+
+Differences from the reference, all documented in DESIGN.md:
+  * `dyn_res` / `cost_grad` are accepted positionally (qp.py:24) but the fused kernel
+    evaluates the linear forms dyn_res(x) = A x - b and cost_grad(x) = Q x + p on chip;
+    pass `check_callables=True` to verify a supplied closure against them at one point.
+  * termination is per problem, not batch-coupled (include/dqp.h).
+  * `check_Q_spd` uses the kernel's Cholesky status instead of B host-side eig calls.
+  * solver=QPSolvers.CVXPY is not available (cvxpy is an offline oracle in the reference).
+"""
+import ctypes
+from enum import Enum
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .util import expandParam, extract_nBatch
+
+INACC_ERR = """
+--------
+qpth warning: Returning an inaccurate and potentially incorrect solution.
+
+Some residual is large.
+Your problem may be infeasible or difficult.
+--------
+"""
+
+
+class QPSolvers(Enum):
+    PDIPM_BATCHED = 1
+    CVXPY = 2
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None and t.numel() > 0 else ctypes.c_void_p(0)
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _prep(t, nd):
+    """-> (contiguous fp64 tensor, batch stride in elements; 0 when shared)."""
+    t = t.detach()
+    if t.dtype != torch.float64:
+        t = t.double()
+    t = t.contiguous()
+    if t.numel() == 0:
+        return t, 0
+    if t.dim() == nd:
+        return t, t[0].numel()
+    if t.dim() == nd - 1:
+        return t, 0
+    raise RuntimeError("Unexpected number of dimensions.")
+
+
+def _require_gpu(*ts):
+    for t in ts:
+        if t is not None and t.numel() > 0 and not t.is_cuda:
+            raise RuntimeError(
+                "diff_qp_mpc_amd operators run only on a GPU (HIP); got a %s tensor. "
+                "There is no CPU fallback." % t.device)
+
+
+def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim):
+    _require_gpu(Q_, p_, G_, h_, A_, b_)
+    lib = _lib.load()
+    nBatch = extract_nBatch(Q_, p_, G_, h_, A_, b_)
+    Q, sQ = _prep(Q_, 3)
+    p, sp = _prep(p_, 2)
+    G, sG = _prep(G_, 3)
+    h, sh = _prep(h_, 2)
+    A, sA = _prep(A_, 3)
+    b, sb = _prep(b_, 2)
+    nineq, nz = G.shape[-2], G.shape[-1]
+    neq = A.shape[-2] if A.numel() > 0 else 0
+    assert neq > 0 or nineq > 0                                   # qp.py:90
+    dev = Q.device
+    dims = _lib.dqp_dims(nBatch, nz, nineq, neq, sQ, sp, sG, sh, sA, sb)
+    opts = _lib.dqp_opts(eps, maxIter, notImprovedLim, 0, 0)
+    kw = dict(dtype=torch.float64, device=dev)
+    zhat = torch.empty(nBatch, nz, **kw)
+    lam = torch.empty(nBatch, nineq, **kw)
+    slack = torch.empty(nBatch, nineq, **kw)
+    nu = torch.empty(nBatch, neq, **kw)
+    info = torch.empty(nBatch, 2, dtype=torch.int32, device=dev)
+    resid = torch.empty(nBatch, **kw)
+    with torch.cuda.device(dev):
+        rc = lib.dqp_qp_forward(ctypes.byref(dims), ctypes.byref(opts), _ptr(Q), _ptr(p), _ptr(G),
+                                _ptr(h), _ptr(A), _ptr(b), _ptr(zhat), _ptr(lam), _ptr(nu),
+                                _ptr(slack), _ptr(info), _ptr(resid), ctypes.c_void_p(0),
+                                _stream(dev))
+    _lib.check(rc, "dqp_qp_forward")
+    return zhat, lam, nu, slack, info, resid, (Q, G, A, dims)
+
+
+def _backward_impl(saved, zhat, lam, nu, slack, dl_dzhat, need, flags):
+    lib = _lib.load()
+    Q, G, A, dims = saved
+    nBatch, nz, nineq, neq = dims.nbatch, dims.nz, dims.nineq, dims.neq
+    dev = Q.device
+    kw = dict(dtype=torch.float64, device=dev)
+    g = dl_dzhat.detach().double().contiguous()
+    dQ = torch.empty(nBatch, nz, nz, **kw) if need[0] else None
+    dp = torch.empty(nBatch, nz, **kw) if need[1] else None
+    dG = torch.empty(nBatch, nineq, nz, **kw) if need[2] else None
+    dh = torch.empty(nBatch, nineq, **kw) if need[3] else None
+    dA = torch.empty(nBatch, neq, nz, **kw) if (need[4] and neq > 0) else None
+    db = torch.empty(nBatch, neq, **kw) if (need[5] and neq > 0) else None
+    opts = _lib.dqp_opts(0.0, 0, 0, flags, 0)
+    with torch.cuda.device(dev):
+        rc = lib.dqp_qp_backward(ctypes.byref(dims), ctypes.byref(opts), _ptr(Q), _ptr(G), _ptr(A),
+                                 _ptr(zhat), _ptr(lam), _ptr(nu), _ptr(slack), _ptr(g),
+                                 _ptr(dQ), _ptr(dp), _ptr(dG), _ptr(dh), _ptr(dA), _ptr(db),
+                                 ctypes.c_void_p(0), ctypes.c_void_p(0), _stream(dev))
+    _lib.check(rc, "dqp_qp_backward")
+    return dQ, dp, dG, dh, dA, db
+
+
+def _check_callables(Q, p, A, b, dyn_res, cost_grad, nBatch):
+    Qe, _ = expandParam(Q, nBatch, 3)
+    x = torch.randn(nBatch, Qe.shape[-1], dtype=Qe.dtype, device=Qe.device)
+    if cost_grad is not None:
+        want = torch.bmm(Qe, x.unsqueeze(-1)).squeeze(-1) + p
+        if not torch.allclose(cost_grad(x), want, rtol=1e-8, atol=1e-10):
+            raise RuntimeError("cost_grad(x) != Qx + p: only the linear form is fused on chip")
+    if dyn_res is not None and A.numel() > 0:
+        Ae, _ = expandParam(A, nBatch, 3)
+        want = torch.bmm(Ae, x.unsqueeze(-1)).squeeze(-1) - b
+        if not torch.allclose(dyn_res(x), want, rtol=1e-8, atol=1e-10):
+            raise RuntimeError("dyn_res(x) != Ax - b: only the linear form is fused on chip")
+
+
+def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3, maxIter=20,
+               solver=QPSolvers.PDIPM_BATCHED, check_Q_spd=True, check_callables=False):
+    """Factory with the reference's signature (qpth/qp.py:19-21); returns a callable
+    `(Q, p, G, h, A, b, dyn_res=None, cost_grad=None) -> zhat (nBatch, nz)`."""
+    if solver != QPSolvers.PDIPM_BATCHED:
+        raise NotImplementedError("only QPSolvers.PDIPM_BATCHED is implemented on MI355X")
+
+    class QPFunctionFn(Function):
+        @staticmethod
+        def forward(ctx, Q_, p_, G_, h_, A_, b_, dyn_res=None, cost_grad=None):
+            nBatch = extract_nBatch(Q_, p_, G_, h_, A_, b_)
+            if check_callables:
+                _check_callables(Q_, p_, A_, b_, dyn_res, cost_grad, nBatch)
+            zhat, lam, nu, slack, info, resid, saved = _forward_impl(
+                Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim)
+            if check_Q_spd:
+                st = info[:, 0]
+                if bool((st == _lib.DQP_STATUS_Q_NOT_PD).any()):
+                    raise RuntimeError('Q is not SPD.')              # qp.py:86
+            if verbose >= 0:
+                if bool((resid.max() > 1.0)):                        # batch.py:142-143
+                    print(INACC_ERR)
+            ctx.saved = saved
+            ctx.lams, ctx.nus, ctx.slacks, ctx.info = lam, nu, slack, info
+            ctx.shared = tuple(t.numel() > 0 and t.dim() == nd - 1 for t, nd in
+                               zip((Q_, p_, G_, h_, A_, b_), (3, 2, 3, 2, 3, 2)))
+            ctx.neq = saved[3].neq
+            ctx.out_dtype = Q_.dtype
+            ctx.save_for_backward(zhat)
+            return zhat.to(Q_.dtype)
+
+        @staticmethod
+        def backward(ctx, dl_dzhat):
+            zhat, = ctx.saved_tensors
+            need = ctx.needs_input_grad[:6]
+            grads = list(_backward_impl(ctx.saved, zhat, ctx.lams, ctx.nus, ctx.slacks,
+                                        dl_dzhat, need, 0))
+            for i, g in enumerate(grads):
+                if g is None:
+                    continue
+                if ctx.shared[i]:
+                    g = g.mean(0)                                    # qp.py:160-178
+                grads[i] = g.to(ctx.out_dtype)
+            return tuple(grads) + (None, None)
+
+    def apply(Q, p, G, h, A, b, dyn_res=None, cost_grad=None):
+        return QPFunctionFn.apply(Q, p, G, h, A, b, dyn_res, cost_grad)
+
+    return apply
+
+
+def DenseQPFunction(bsz=1, eps=1e-12, verbose=0, notImprovedLim=3, maxIter=20):
+    """Factory with the reference's signature (qpth/qp.py:187-188); returns a callable
+    `(Q, p, G, h, A, b, dyn_res, cost_grad=None) -> zhat`.  All six parameters must be
+    batched (the reference's preprocess(), qp.py:195-217, does no expandParam).
+
+    The reference solves the same Newton systems through a regularised (1e-7) full-KKT LU
+    with one refinement step (batch_LU.py:212-244); here they are solved by the fused
+    block-Cholesky kernel, and backward uses d = lam/slack without QPFunction's clamps
+    (qp.py:246-250)."""
+
+    class Solver(Function):
+        @staticmethod
+        def forward(ctx, Q, p, G, h, A, b, dyn_res=None, cost_grad=None):
+            for t, nd in zip((Q, p, G, h, A, b), (3, 2, 3, 2, 3, 2)):
+                if t.dim() != nd:
+                    raise RuntimeError("DenseQPFunction needs batched parameters")
+            zhat, lam, nu, slack, info, resid, saved = _forward_impl(
+                Q, p, G, h, A, b, eps, maxIter, notImprovedLim)
+            ctx.saved = saved
+            ctx.lams, ctx.nus, ctx.slacks, ctx.info = lam, nu, slack, info
+            ctx.out_dtype = Q.dtype
+            ctx.save_for_backward(zhat)
+            return zhat.to(Q.dtype)
+
+        @staticmethod
+        def backward(ctx, dl_dzhat):
+            zhat, = ctx.saved_tensors
+            need = ctx.needs_input_grad[:6]
+            grads = _backward_impl(ctx.saved, zhat, ctx.lams, ctx.nus, ctx.slacks, dl_dzhat,
+                                   need, _lib.DQP_FLAG_DENSE_BACKWARD)
+            grads = tuple(None if g is None else g.to(ctx.out_dtype) for g in grads)
+            return grads + (None, None)
+
+    def apply(Q, p, G, h, A, b, dyn_res=None, cost_grad=None):
+        return Solver.apply(Q, p, G, h, A, b, dyn_res, cost_grad)
+
+    return apply

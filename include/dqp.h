@@ -1,0 +1,117 @@
+/*
+ * dqp.h -- C ABI of the MI355X-native differentiable batched QP solver (libdqp_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of swami1995/diff-qp-mpc.  The reference
+ * has no C/FFI layer on this path (its boundary is a Python torch.autograd.Function built by
+ * a factory closure); each entry point below names the reference interface it replaces, and
+ * INTEGRATION.md shows the ~100-line Python binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers (HIP), fp64, row-major, contiguous inside one batch
+ *     element.  The caller owns every buffer; the library allocates nothing and keeps no state.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls only enqueue
+ *     work; they never synchronise, allocate or copy, so they are hipGraph-capturable.
+ *   - A batch stride of 0 means "this parameter is shared by all batch elements" (the
+ *     reference's expandParam rule, qpth/util.py:36-43).
+ *   - Return value: DQP_OK or a negative DQP_ERR_* for argument errors detected on the host.
+ *     Per-problem numerical status is written to `info` on the device (see below).
+ *   - Sizes: this build solves QPs with nz, nineq, neq <= DQP_MAX_DIM on the fused
+ *     one-wavefront-per-QP kernels; larger problems return DQP_ERR_TOO_LARGE.
+ */
+#ifndef DQP_H_
+#define DQP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DQP_VERSION 100 /* 0.1.0 */
+#define DQP_MAX_DIM 64
+
+enum {
+    DQP_OK = 0,
+    DQP_ERR_BAD_ARG = -1,    /* null pointer, negative size, nineq == 0 ...              */
+    DQP_ERR_TOO_LARGE = -2,  /* a dimension exceeds DQP_MAX_DIM or LDS capacity           */
+    DQP_ERR_LAUNCH = -3,     /* hipLaunchKernel / hipFuncSetAttribute reported an error   */
+    DQP_ERR_NO_DEVICE = -4
+};
+
+/* per-problem status written to info[2*i + 0] */
+enum {
+    DQP_STATUS_OK = 0,
+    DQP_STATUS_Q_NOT_PD = 1,    /* reference: RuntimeError('Q is not SPD.') qp.py:86 /
+                                   LU(Q) failure batch.py:381-388                          */
+    DQP_STATUS_A_RANK_DEF = 2   /* A Q^-1 A^T not positive definite (A rank deficient)    */
+};
+
+/* flags */
+#define DQP_FLAG_DENSE_BACKWARD 1u /* backward of DenseQPFunction (qp.py:239-270): d = lam/slack
+                                      without the 1e-8 clamps of QPFunction (qp.py:149)   */
+
+typedef struct dqp_dims {
+    int32_t nbatch;
+    int32_t nz;
+    int32_t nineq;
+    int32_t neq;       /* 0 = no equality constraints (A, b may be NULL)                   */
+    /* batch strides in ELEMENTS (doubles); 0 = shared across the batch                    */
+    int64_t stride_Q, stride_p, stride_G, stride_h, stride_A, stride_b;
+} dqp_dims;
+
+typedef struct dqp_opts {
+    double eps;               /* qp.py:19  eps=1e-12                                       */
+    int32_t max_iter;         /* qp.py:20  maxIter=20                                      */
+    int32_t not_improved_lim; /* qp.py:19  notImprovedLim=3                                */
+    uint32_t flags;
+    int32_t reserved;
+} dqp_opts;
+
+int dqp_version(void);
+const char *dqp_error_string(int code);
+
+/* Bytes of caller-provided device workspace the calls below need (0 in this build: all
+ * solver state lives in LDS/registers). */
+size_t dqp_workspace_bytes(const dqp_dims *dims);
+
+/*
+ * Replaces: qpth.qp.QPFunction(...).forward  (qpth/qp.py:24-126) =
+ *           pdipm_b.pre_factor_kkt + pdipm_b.forward (qpth/solvers/pdipm/batch.py:377-428,
+ *           46-208), with dyn_res(x) = A x - b and cost_grad(x) = Q x + p; and the forward of
+ *           qpth.qp.DenseQPFunction (qpth/qp.py:219-237 + batch_LU.py:29-201), which solves the
+ *           same Newton systems through a regularised full-KKT LU.
+ * Outputs: zhat (B,nz); lam (B,nineq), nu (B,neq), slack (B,nineq) -- what the reference
+ *          stashes on ctx for backward (qp.py:95,125); info (B,2) int32 = {status, PDIPM
+ *          iterations run}; best_resid (B) or NULL.
+ * Termination is per problem (reference: batch-coupled, batch.py:127-144): a problem stops
+ * after not_improved_lim consecutive non-improving iterations, when its best residual < eps,
+ * when mu > 1e32, or after max_iter iterations; the best-residual iterate is returned.
+ */
+int dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts,
+                   const double *Q, const double *p, const double *G, const double *h,
+                   const double *A, const double *b,
+                   double *zhat, double *lam, double *nu, double *slack,
+                   int32_t *info, double *best_resid,
+                   void *workspace, void *stream);
+
+/*
+ * Replaces: QPFunctionFn.backward (qpth/qp.py:128-183) = factor_kkt + solve_kkt
+ *           (batch.py:434-469, 351-374) with rhs (dl_dzhat, 0, 0, 0) and the outer-product
+ *           gradient formulas; with DQP_FLAG_DENSE_BACKWARD, DenseQPFunction's Solver.backward
+ *           (qp.py:239-270).
+ * Writes PER-SAMPLE gradients dQ (B,nz,nz) dp (B,nz) dG (B,nineq,nz) dh (B,nineq)
+ * dA (B,neq,nz) db (B,neq); the caller applies .mean(0) for parameters that were shared
+ * (qp.py:160-178).  Any gradient pointer may be NULL to skip it.
+ */
+int dqp_qp_backward(const dqp_dims *dims, const dqp_opts *opts,
+                    const double *Q, const double *G, const double *A,
+                    const double *zhat, const double *lam, const double *nu,
+                    const double *slack, const double *dl_dzhat,
+                    double *dQ, double *dp, double *dG, double *dh, double *dA, double *db,
+                    int32_t *info, void *workspace, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DQP_H_ */

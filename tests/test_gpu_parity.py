@@ -1,0 +1,192 @@
+"""GPU parity tests (run on a real MI355X with `-m gpu`): the HIP path, called through the
+C ABI, against (1) the golden vectors captured from the reference and (2) the CPU oracle on
+seeded inputs, plus size-independent KKT properties at the full benchmark size.
+
+Tolerances (fp64), stated per SURVEY.md §8c: the reference's own two solvers agree to 3e-13 on
+zhat and 5e-6 on gradients; termination here is per problem instead of batch-coupled, so
+parity is a float tolerance, never iteration-exact:
+    zhat            rtol 1e-6  atol 1e-8
+    lam, nu, slack  rtol 1e-5  atol 1e-7
+    gradients       rtol 1e-4  atol 1e-6
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+DENSE = [c for c in CASES if "dense_zhat" in np.load(os.path.join(GOLDEN, c + ".npz")).files]
+
+ZT = dict(rtol=1e-6, atol=1e-8)
+DT = dict(rtol=1e-5, atol=1e-7)
+GT = dict(rtol=1e-4, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def dqp():
+    assert torch.cuda.is_available(), "these tests need a GPU"
+    import diff_qp_mpc_amd
+    from diff_qp_mpc_amd import _lib
+    _lib.load()          # fails loudly if the HIP library is missing
+    return diff_qp_mpc_amd
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def dev(a, grad=True):
+    t = torch.tensor(np.asarray(a), dtype=torch.float64, device="cuda")
+    return t.requires_grad_() if grad else t
+
+
+def family_R(seed, B, nz, nineq, neq):
+    g = torch.Generator().manual_seed(seed)
+    L = torch.randn(B, nz, nz, generator=g, dtype=torch.float64)
+    Q = L @ L.transpose(1, 2) + 1e-3 * torch.eye(nz, dtype=torch.float64)
+    G = torch.randn(B, nineq, nz, generator=g, dtype=torch.float64)
+    z0 = torch.randn(B, nz, generator=g, dtype=torch.float64)
+    s0 = torch.rand(B, nineq, generator=g, dtype=torch.float64)
+    A = torch.randn(B, neq, nz, generator=g, dtype=torch.float64)
+    p = torch.randn(B, nz, generator=g, dtype=torch.float64)
+    h = (G @ z0.unsqueeze(-1)).squeeze(-1) + s0
+    b = (A @ z0.unsqueeze(-1)).squeeze(-1)
+    return [t.numpy() for t in (Q, p, G, h, A, b)]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_forward_backward_vs_golden(dqp, name):
+    g = load(name)
+    neq = g["nu"].shape[1]
+    ins = [dev(g["in_" + k]) for k in "QpGhAb"]
+    for tag in ("ones", "rand"):
+        for t in ins:
+            t.grad = None
+        zhat = dqp.QPFunction(check_Q_spd=True, verbose=-1)(*ins)
+        np.testing.assert_allclose(zhat.detach().cpu().numpy(), g["zhat"], **ZT)
+        zhat.backward(dev(g["ct_" + tag], grad=False))
+        for k, t in zip("QpGhAb", ins):
+            if neq == 0 and k in "Ab":
+                continue
+            np.testing.assert_allclose(t.grad.cpu().numpy(), g["d%s_%s" % (k, tag)],
+                                       err_msg="d%s (%s)" % (k, tag), **GT)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_duals_vs_golden_through_c_abi(dqp, name):
+    """lam / nu / slack straight from the C ABI entry point."""
+    from diff_qp_mpc_amd import qp as qpmod
+    g = load(name)
+    ins = [dev(g["in_" + k], grad=False) for k in "QpGhAb"]
+    zhat, lam, nu, slack, info, resid, _ = qpmod._forward_impl(*ins, 1e-12, 20, 3)
+    assert int(info[:, 0].abs().max()) == 0
+    np.testing.assert_allclose(zhat.cpu().numpy(), g["zhat"], **ZT)
+    np.testing.assert_allclose(lam.cpu().numpy(), g["lam"], **DT)
+    np.testing.assert_allclose(slack.cpu().numpy(), g["slack"], **DT)
+    if g["nu"].shape[1]:
+        np.testing.assert_allclose(nu.cpu().numpy(), g["nu"], **DT)
+    assert float(resid.max()) < 1e-6
+
+
+@pytest.mark.parametrize("name", DENSE)
+def test_dense_vs_golden(dqp, name):
+    g = load(name)
+    ins = [dev(g["in_" + k]) for k in "QpGhAb"]
+    for tag in ("ones", "rand"):
+        for t in ins:
+            t.grad = None
+        zhat = dqp.DenseQPFunction()(*ins, None)
+        np.testing.assert_allclose(zhat.detach().cpu().numpy(), g["dense_zhat"], **ZT)
+        zhat.backward(dev(g["ct_" + tag], grad=False))
+        for k, t in zip("QpGhAb", ins):
+            np.testing.assert_allclose(t.grad.cpu().numpy(), g["dense_d%s_%s" % (k, tag)],
+                                       err_msg="dense d%s (%s)" % (k, tag), **GT)
+
+
+@pytest.mark.parametrize("shape", [(64, 30, 30, 15), (33, 40, 20, 30), (17, 7, 64, 3),
+                                   (9, 64, 64, 32), (5, 1, 1, 1), (130, 12, 9, 0)])
+def test_vs_oracle_seeded(dqp, shape):
+    B, nz, nineq, neq = shape
+    Q, p, G, h, A, b = family_R(100 + nz, B, nz, nineq, max(neq, 1))
+    if neq == 0:
+        A = np.zeros((B, 0, nz)); b = np.zeros((B, 0))
+    o = oracle.qp_forward(Q, p, G, h, A, b)
+    ins = [dev(a) for a in (Q, p, G, h, A, b)]
+    zhat = dqp.QPFunction(check_Q_spd=False, verbose=-1)(*ins)
+    np.testing.assert_allclose(zhat.detach().cpu().numpy(), o["zhat"], **ZT)
+    ct = np.random.default_rng(0).standard_normal((B, nz))
+    zhat.backward(dev(ct, grad=False))
+    og = oracle.qp_backward(Q, G, A, o["zhat"], o["lam"], o["nu"], o["slack"], ct)
+    for k, t in zip("QpGhAb", ins):
+        if neq == 0 and k in "Ab":
+            continue
+        np.testing.assert_allclose(t.grad.cpu().numpy(), og["d" + k], err_msg="d" + k, **GT)
+
+
+def test_full_size_properties_and_oracle(dqp):
+    """BASELINE metric config: B=4096, nz=30, nineq=30, neq=15 (family R, seed 0)."""
+    B, nz, nineq, neq = 4096, 30, 30, 15
+    Q, p, G, h, A, b = family_R(0, B, nz, nineq, neq)
+    ins = [dev(a) for a in (Q, p, G, h, A, b)]
+    from diff_qp_mpc_amd import qp as qpmod
+    zhat, lam, nu, slack, info, resid, _ = qpmod._forward_impl(*ins, 1e-12, 20, 3)
+    assert int(info[:, 0].abs().max()) == 0
+    Qd, pd, Gd, hd, Ad, bd = [t.detach() for t in ins]
+    mv = lambda M, x: torch.bmm(M, x.unsqueeze(-1)).squeeze(-1)
+    mtv = lambda M, x: torch.bmm(M.transpose(1, 2), x.unsqueeze(-1)).squeeze(-1)
+    stat = mv(Qd, zhat) + pd + mtv(Gd, lam) + mtv(Ad, nu)
+    scale = 1.0 + mv(Qd, zhat).abs().max()
+    assert float(stat.abs().max() / scale) < 1e-8              # stationarity
+    assert float((mv(Ad, zhat) - bd).abs().max()) < 1e-8       # equality feasibility
+    assert float((mv(Gd, zhat) + slack - hd).abs().max()) < 1e-8
+    assert float(lam.min()) > 0 and float(slack.min()) > 0
+    assert float((lam * slack).abs().max()) < 1e-8             # complementarity
+    # same batch through the oracle (batch-coupled termination) -> float tolerance
+    o = oracle.qp_forward(Q, p, G, h, A, b)
+    np.testing.assert_allclose(zhat.cpu().numpy(), o["zhat"], **ZT)
+    np.testing.assert_allclose(lam.cpu().numpy(), o["lam"], **DT)
+    # backward: linearity in the cotangent + oracle
+    zf = dqp.QPFunction(check_Q_spd=False, verbose=-1)(*ins)
+    ct = torch.randn(B, nz, dtype=torch.float64, device="cuda",
+                     generator=torch.Generator(device="cuda").manual_seed(1))
+    g1 = torch.autograd.grad(zf, ins, ct, retain_graph=True)
+    g2 = torch.autograd.grad(zf, ins, 2.0 * ct, retain_graph=True)
+    for a, c in zip(g1, g2):
+        assert torch.allclose(2.0 * a, c, rtol=1e-12, atol=1e-14)
+    og = oracle.qp_backward(Q, G, A, o["zhat"], o["lam"], o["nu"], o["slack"], ct.cpu().numpy())
+    for k, t in zip("QpGhAb", g1):
+        np.testing.assert_allclose(t.cpu().numpy(), og["d" + k], err_msg="d" + k, **GT)
+
+
+def test_not_spd_raises(dqp):
+    Q, p, G, h, A, b = family_R(3, 4, 6, 4, 2)
+    Q[2] = -Q[2]
+    ins = [dev(a, grad=False) for a in (Q, p, G, h, A, b)]
+    with pytest.raises(RuntimeError, match="Q is not SPD"):
+        dqp.QPFunction(check_Q_spd=True, verbose=-1)(*ins)
+
+
+def test_cpu_tensors_fail_loudly(dqp):
+    Q, p, G, h, A, b = [torch.tensor(a) for a in family_R(3, 2, 4, 3, 1)]
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dqp.QPFunction(check_Q_spd=False)(Q, p, G, h, A, b)
+
+
+def test_empty_batch_and_bad_dims(dqp):
+    import ctypes
+    from diff_qp_mpc_amd import _lib
+    lib = _lib.load()
+    d = _lib.dqp_dims(4, 65, 3, 0, 0, 0, 0, 0, 0, 0)
+    z = ctypes.c_void_p(0)
+    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 14)) == -2      # too large
+    d = _lib.dqp_dims(4, 5, 0, 0, 0, 0, 0, 0, 0, 0)
+    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 14)) == -1      # nineq == 0
+    d = _lib.dqp_dims(0, 5, 3, 0, 0, 0, 0, 0, 0, 0)
+    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 14)) == 0       # empty batch
