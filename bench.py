@@ -75,7 +75,7 @@ class HotPath:
         self.dG = torch.empty(B, NINEQ, NZ, **kw); self.dh = torch.empty(B, NINEQ, **kw)
         self.dA = torch.empty(B, NEQ, NZ, **kw); self.db = torch.empty(B, NEQ, **kw)
         self.dims = _lib.dqp_dims(B, NZ, NINEQ, NEQ, NZ * NZ, NZ, NINEQ * NZ, NINEQ, NEQ * NZ, NEQ)
-        self.opts = _lib.dqp_opts(1e-12, 20, 3, 0, 0)
+        self.opts = _lib.dqp_opts(1e-12, 1e-10, 20, 3, 0, 0)
         self.stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         self.fargs = [P(t) for t in (self.Q, self.p, self.G, self.h, self.A, self.b, self.zhat,

@@ -20,7 +20,8 @@ class dqp_dims(ctypes.Structure):
 
 
 class dqp_opts(ctypes.Structure):
-    _fields_ = [("eps", ctypes.c_double), ("max_iter", ctypes.c_int32),
+    _fields_ = [("eps", ctypes.c_double), ("stall_tol", ctypes.c_double),
+                ("max_iter", ctypes.c_int32),
                 ("not_improved_lim", ctypes.c_int32), ("flags", ctypes.c_uint32),
                 ("reserved", ctypes.c_int32)]
 

@@ -44,7 +44,7 @@ struct KParams {
     int32_t *info;
     int B, N, M, E;
     int ldz, ldm, lde, ldt;
-    double eps;
+    double eps, stallTol;
     int maxIter, notImprovedLim;
     unsigned flags;
 };
@@ -205,8 +205,8 @@ __device__ __forceinline__ Lds carve(double *sm, const KParams &P)
     s.At = s.Gh + P.M * P.ldz;
     s.L1 = s.At + P.E * P.ldz;
     s.R = s.L1 + P.E * P.lde;
-    s.T = s.R + P.M * P.ldm;
-    s.W = s.T + P.M * P.ldt;
+    s.W = s.R;   // W = Gh At^T is dead before R is written (qp_setup), so they share storage
+    s.T = s.R + P.M * (P.ldm > P.lde ? P.ldm : P.lde);
     return s;
 }
 
@@ -417,7 +417,9 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
         } else {
             nNotImproved += 1;
         }
-        if (nNotImproved == P.notImprovedLim || best < P.eps || mu > 1e32) break;
+        if ((nNotImproved >= P.notImprovedLim && best < P.stallTol) || best < P.eps ||
+            mu > 1e32 || !(fabs(resid) < INFINITY))
+            break;
 
         const double dinv = inM ? s / z : 0.0;                          // 1/d, d = z/s
         rdT = factor_T(P, S, dinv, lane);
@@ -532,12 +534,13 @@ int fill_params(const dqp_dims *d, const dqp_opts *o, KParams &P, size_t &lds_by
     P.sQ = d->stride_Q; P.sp = d->stride_p; P.sG = d->stride_G;
     P.sh = d->stride_h; P.sA = d->stride_A; P.sb = d->stride_b;
     P.eps = o ? o->eps : 1e-12;
+    P.stallTol = o ? o->stall_tol : 1e-10;
     P.maxIter = o ? o->max_iter : 20;
     P.notImprovedLim = o ? o->not_improved_lim : 3;
     P.flags = o ? o->flags : 0u;
     size_t n = (size_t)P.N * P.ldz + (size_t)P.M * P.ldz + (size_t)P.E * P.ldz +
-               (size_t)P.E * P.lde + (size_t)P.M * P.ldm + (size_t)P.M * P.ldt +
-               (size_t)P.M * P.lde;
+               (size_t)P.E * P.lde + (size_t)P.M * (P.ldm > P.lde ? P.ldm : P.lde) +
+               (size_t)P.M * P.ldt;
     lds_bytes = n * sizeof(double);
     if (lds_bytes > 160 * 1024) return DQP_ERR_TOO_LARGE;
     return DQP_OK;

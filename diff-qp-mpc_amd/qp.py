@@ -5,7 +5,7 @@ Differences from the reference, all documented in DESIGN.md:
   * `dyn_res` / `cost_grad` are accepted positionally (qp.py:24) but the fused kernel
     evaluates the linear forms dyn_res(x) = A x - b and cost_grad(x) = Q x + p on chip;
     pass `check_callables=True` to verify a supplied closure against them at one point.
-  * termination is per problem, not batch-coupled (include/dqp.h).
+  * termination is per problem, not batch-coupled (include/dqp.h, DESIGN.md §termination).
   * `check_Q_spd` uses the kernel's Cholesky status instead of B host-side eig calls.
   * solver=QPSolvers.CVXPY is not available (cvxpy is an offline oracle in the reference).
 """
@@ -26,6 +26,10 @@ Some residual is large.
 Your problem may be infeasible or difficult.
 --------
 """
+
+
+# per-problem early exit only once the best residual is below this (include/dqp.h)
+STALL_TOL = 1e-10
 
 
 class QPSolvers(Enum):
@@ -79,7 +83,7 @@ def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim):
     assert neq > 0 or nineq > 0                                   # qp.py:90
     dev = Q.device
     dims = _lib.dqp_dims(nBatch, nz, nineq, neq, sQ, sp, sG, sh, sA, sb)
-    opts = _lib.dqp_opts(eps, maxIter, notImprovedLim, 0, 0)
+    opts = _lib.dqp_opts(eps, STALL_TOL, maxIter, notImprovedLim, 0, 0)
     kw = dict(dtype=torch.float64, device=dev)
     zhat = torch.empty(nBatch, nz, **kw)
     lam = torch.empty(nBatch, nineq, **kw)
@@ -109,7 +113,7 @@ def _backward_impl(saved, zhat, lam, nu, slack, dl_dzhat, need, flags):
     dh = torch.empty(nBatch, nineq, **kw) if need[3] else None
     dA = torch.empty(nBatch, neq, nz, **kw) if (need[4] and neq > 0) else None
     db = torch.empty(nBatch, neq, **kw) if (need[5] and neq > 0) else None
-    opts = _lib.dqp_opts(0.0, 0, 0, flags, 0)
+    opts = _lib.dqp_opts(0.0, 0.0, 0, 0, flags, 0)
     with torch.cuda.device(dev):
         rc = lib.dqp_qp_backward(ctypes.byref(dims), ctypes.byref(opts), _ptr(Q), _ptr(G), _ptr(A),
                                  _ptr(zhat), _ptr(lam), _ptr(nu), _ptr(slack), _ptr(g),

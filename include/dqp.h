@@ -62,6 +62,7 @@ typedef struct dqp_dims {
 
 typedef struct dqp_opts {
     double eps;               /* qp.py:19  eps=1e-12                                       */
+    double stall_tol;         /* per-problem early exit needs best_resid < stall_tol (1e-10) */
     int32_t max_iter;         /* qp.py:20  maxIter=20                                      */
     int32_t not_improved_lim; /* qp.py:19  notImprovedLim=3                                */
     uint32_t flags;
@@ -84,9 +85,14 @@ size_t dqp_workspace_bytes(const dqp_dims *dims);
  * Outputs: zhat (B,nz); lam (B,nineq), nu (B,neq), slack (B,nineq) -- what the reference
  *          stashes on ctx for backward (qp.py:95,125); info (B,2) int32 = {status, PDIPM
  *          iterations run}; best_resid (B) or NULL.
- * Termination is per problem (reference: batch-coupled, batch.py:127-144): a problem stops
- * after not_improved_lim consecutive non-improving iterations, when its best residual < eps,
- * when mu > 1e32, or after max_iter iterations; the best-residual iterate is returned.
+ * Termination is per problem.  The reference's rule is batch-coupled (batch.py:127-144: stop
+ * when NO sample improved for not_improved_lim consecutive iterations, so in a large batch
+ * every sample effectively runs max_iter iterations).  Here a problem stops when (a) it has
+ * not improved for not_improved_lim consecutive iterations AND its best residual is already
+ * below stall_tol (converged, stagnating at round-off), (b) its best residual < eps, (c) its
+ * residual is no longer finite (the iterate can never recover; the reference keeps spinning
+ * on NaNs), (d) mu > 1e32, or (e) after max_iter iterations.  The best-residual iterate is
+ * returned, as in batch.py:119-140,208.
  */
 int dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts,
                    const double *Q, const double *p, const double *G, const double *h,

@@ -368,9 +368,13 @@ API int dqp_oracle_qp_forward(int B, int nz, int nineq, int neq,
                               const double *h, const double *A, const double *b,
                               double eps, int notImprovedLim, int maxIter,
                               double *zhat, double *lam, double *nu, double *slack,
-                              int *iters_out, double *best_resid, int nthreads)
+                              int *iters_out, double *best_resid, double *resid_hist,
+                              int nthreads)
 {
+    /* resid_hist (B, maxIter) or NULL: diagnostic trace of `resids` (batch.py:108) per
+     * iteration, NaN where the batch had already stopped. */
     nthreads = set_threads(nthreads);
+    if (resid_hist) for (size_t k = 0; k < (size_t)B * maxIter; ++k) resid_hist[k] = NAN;
     const size_t nd = qpws_doubles(nz, nineq, neq);
     const size_t ni = (size_t)nz + neq + nineq + 8;
     double *buf = (double *)malloc(sizeof(double) * nd * B);
@@ -409,6 +413,7 @@ API int dqp_oracle_qp_forward(int B, int nz, int nineq, int neq,
                 for (int k = 0; k < nineq; ++k) w->d[k] = w->z[k] / w->s[k];
                 w->info = factor_T(w);
                 any_info |= (w->info != 0);
+                if (resid_hist) resid_hist[(size_t)i * maxIter + it] = w->resid;
             }
             if (any_info) break;      /* try/except around factor_kkt: return best */
             iters = it + 1;

@@ -59,15 +59,16 @@ def qp_forward(Q, p, G, h, A, b, eps=1e-12, notImprovedLim=3, maxIter=20, nthrea
     A = _c(A) if neq else None
     b = _c(b) if neq else None
     zhat = np.empty((B, nz)); lam = np.empty((B, nineq)); slack = np.empty((B, nineq))
-    nu = np.empty((B, neq)); res = np.empty(B)
+    nu = np.empty((B, neq)); res = np.empty(B); hist = np.empty((B, maxIter))
     it = ctypes.c_int(0)
     rc = lib().dqp_oracle_qp_forward(
         B, nz, nineq, neq, _p(Q), _p(p), _p(G), _p(h), _p(A), _p(b),
         ctypes.c_double(eps), notImprovedLim, maxIter,
-        _p(zhat), _p(lam), _p(nu), _p(slack), ctypes.byref(it), _p(res), nthreads)
+        _p(zhat), _p(lam), _p(nu), _p(slack), ctypes.byref(it), _p(res), _p(hist), nthreads)
     if rc != 0:
         raise RuntimeError("oracle qp_forward failed rc=%d" % rc)
-    return dict(zhat=zhat, lam=lam, nu=nu, slack=slack, iters=it.value, best_resid=res)
+    return dict(zhat=zhat, lam=lam, nu=nu, slack=slack, iters=it.value, best_resid=res,
+                resid_hist=hist)
 
 
 def qp_backward(Q, G, A, zhat, lam, nu, slack, dl_dzhat, nthreads=0):
