@@ -59,62 +59,100 @@ __device__ __forceinline__ double bcast(double v, int src)
     return __hiloint2double(hi, lo);
 }
 
+template <int CTRL> __device__ __forceinline__ double dppd(double v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true);
+}
+
+// all-reduce inside each 16-lane DPP row (row_ror 8/4/2/1), then combine the 4 rows
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dppd<0x128>(v); v += dppd<0x124>(v); v += dppd<0x122>(v); v += dppd<0x121>(v);
+    return (bcast(v, 0) + bcast(v, 16)) + (bcast(v, 32) + bcast(v, 48));
 }
 
 __device__ __forceinline__ double wave_min(double v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o));
-    return v;
+    v = fmin(v, dppd<0x128>(v)); v = fmin(v, dppd<0x124>(v));
+    v = fmin(v, dppd<0x122>(v)); v = fmin(v, dppd<0x121>(v));
+    return fmin(fmin(bcast(v, 0), bcast(v, 16)), fmin(bcast(v, 32), bcast(v, 48)));
 }
 
+// The mat-vecs are unrolled over a compile-time size class C (16/32/64 >= every dimension) in
+// chunks of 8 so that the LDS reads of a chunk are all in flight before the first FMA; indices
+// past the runtime size are clamped (uniform, SALU) and their products masked.
+constexpr int CH = 8;
+
 // y_i = sum_{j<n} M[i][j] x_j for lanes i < m (0 elsewhere).  x: element j on lane j.
+template <int C>
 __device__ __forceinline__ double matvec(const double *Mx, int ld, int m, int n, double x, int lane)
 {
     const double *row = Mx + (lane < m ? lane : 0) * ld;
     double a0 = 0.0, a1 = 0.0;
-    int j = 0;
-    for (; j + 1 < n; j += 2) {
-        a0 = fma(row[j], bcast(x, j), a0);
-        a1 = fma(row[j + 1], bcast(x, j + 1), a1);
+#pragma unroll
+    for (int jb = 0; jb < C; jb += CH) {
+        if (jb < n) {
+            double v[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) v[u] = row[min(jb + u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < CH; u += 2) {
+                a0 = fma(v[u], (jb + u < n) ? bcast(x, jb + u) : 0.0, a0);
+                a1 = fma(v[u + 1], (jb + u + 1 < n) ? bcast(x, jb + u + 1) : 0.0, a1);
+            }
+        }
     }
-    if (j < n) a0 = fma(row[j], bcast(x, j), a0);
     return lane < m ? a0 + a1 : 0.0;
 }
 
 // y_j = sum_{i<m} M[i][j] x_i for lanes j < n (0 elsewhere).  x: element i on lane i.
+template <int C>
 __device__ __forceinline__ double matvecT(const double *Mx, int ld, int m, int n, double x, int lane)
 {
     const double *col = Mx + (lane < n ? lane : 0);
     double a0 = 0.0, a1 = 0.0;
-    int i = 0;
-    for (; i + 1 < m; i += 2) {
-        a0 = fma(col[i * ld], bcast(x, i), a0);
-        a1 = fma(col[(i + 1) * ld], bcast(x, i + 1), a1);
+#pragma unroll
+    for (int ib = 0; ib < C; ib += CH) {
+        if (ib < m) {
+            double v[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) v[u] = col[min(ib + u, m - 1) * ld];
+#pragma unroll
+            for (int u = 0; u < CH; u += 2) {
+                a0 = fma(v[u], (ib + u < m) ? bcast(x, ib + u) : 0.0, a0);
+                a1 = fma(v[u + 1], (ib + u + 1 < m) ? bcast(x, ib + u + 1) : 0.0, a1);
+            }
+        }
     }
-    if (i < m) a0 = fma(col[i * ld], bcast(x, i), a0);
     return lane < n ? a0 + a1 : 0.0;
 }
 
-// y_i = sum_{j<=i} L[i][j] x_j (lower-triangular mat-vec; the strict upper part is not read)
+// y_i = sum_{j<=i} L[i][j] x_j (lower-triangular mat-vec; the strict upper part is masked)
+template <int C>
 __device__ __forceinline__ double trimatvec(const double *L, int ld, int n, double x, int lane)
 {
     const double *row = L + (lane < n ? lane : 0) * ld;
-    double a = 0.0;
-    for (int j = 0; j < n; ++j) {
-        double xj = bcast(x, j);
-        if (j <= lane && lane < n) a = fma(row[j], xj, a);
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int jb = 0; jb < C; jb += CH) {
+        if (jb < n) {
+            double v[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) v[u] = row[min(jb + u, n - 1)];
+#pragma unroll
+            for (int u = 0; u < CH; u += 2) {
+                const double x0 = (jb + u < n) ? bcast(x, jb + u) : 0.0;
+                const double x1 = (jb + u + 1 < n) ? bcast(x, jb + u + 1) : 0.0;
+                a0 = fma(jb + u <= lane ? v[u] : 0.0, x0, a0);
+                a1 = fma(jb + u + 1 <= lane ? v[u + 1] : 0.0, x1, a1);
+            }
+        }
     }
-    return a;
+    return lane < n ? a0 + a1 : 0.0;
 }
 
 // In-place lower Cholesky of the n x n matrix in LDS; rd = 1/L[i][i] on lane i.
-__device__ bool chol_factor(double *L, int ld, int n, int lane, double &rd)
+__device__ __forceinline__ bool chol_factor(double *L, int ld, int n, int lane, double &rd)
 {
     bool ok = true;
     rd = 0.0;
@@ -171,6 +209,56 @@ __device__ __forceinline__ double ldl_solve(const double *T, int ld, int n, doub
     return b;
 }
 
+
+// ---- register-resident T (per-iteration Schur complement) ---------------------------------
+// Lane j holds column j (== row j) of the symmetric matrix in t[0..MAXM).  After ldl_reg(),
+// t[k] for k < lane is L[lane][k] (row of the unit-lower factor), t[i] for i > lane is
+// L[i][lane] (its column), and the return value is 1/D[lane].  All indices are compile-time
+// after unrolling, so t[] stays in VGPRs; the only cross-lane traffic is v_readlane.
+template <int MAXM>
+__device__ __forceinline__ double ldl_reg(double (&t)[MAXM], int n, int lane)
+{
+    double rdiag = 0.0;
+#pragma unroll
+    for (int k = 0; k < MAXM; ++k) {
+        if (k < n) {
+            const double r = 1.0 / bcast(t[k], k);
+            if (lane == k) rdiag = r;
+            const bool act = lane > k;
+            const double c = act ? t[k] : 0.0;   // D_k L[lane][k]; 0 keeps finished lanes intact
+            const double l = c * r;              // L[lane][k]
+            t[k] = act ? l : t[k];
+#pragma unroll
+            for (int i = k + 1; i < MAXM; ++i)
+                if (i < n) t[i] = fma(-bcast(l, i), c, t[i]);
+        }
+    }
+    // lane j still holds D_j L[i][j] in t[i], i > j (its column as of step j): scale to L[i][j]
+#pragma unroll
+    for (int i = 1; i < MAXM; ++i) t[i] = (i > lane) ? t[i] * rdiag : t[i];
+    return rdiag;
+}
+
+template <int MAXM>
+__device__ __forceinline__ double ldl_reg_solve(const double (&t)[MAXM], int n, double b,
+                                                double rdiag, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < MAXM - 1; ++k)
+        if (k < n - 1) {
+            const double bk = bcast(b, k);
+            if (lane > k) b = fma(-t[k], bk, b);
+        }
+    b *= rdiag;
+#pragma unroll
+    for (int k = MAXM - 1; k > 0; --k)
+        if (k < n) {
+            const double bk = bcast(b, k);
+            if (lane < k) b = fma(-t[k], bk, b);
+        }
+    return lane < n ? b : 0.0;
+}
+
 // L y = b (L lower, non-unit; rd = reciprocal diagonal, element i on lane i)
 __device__ __forceinline__ double trsv_L(const double *L, int ld, int n, double b, double rd, int lane)
 {
@@ -213,7 +301,7 @@ __device__ __forceinline__ Lds carve(double *sm, const KParams &P)
 // One-time factorisations (reference: pre_factor_kkt, batch.py:377-428).
 // On return: Lq (chol Q), Gh = G Lq^-T, At = L1^-1 A Lq^-T, L1 = chol(A Q^-1 A^T),
 // R = Gh (I - At^T At) Gh^T; rdq / rd1 = reciprocal diagonals of Lq / L1 on lane i.
-__device__ int qp_setup(const KParams &P, const Lds &S, int qp, int lane, double &rdq, double &rd1)
+__device__ __forceinline__ int qp_setup(const KParams &P, const Lds &S, int qp, int lane, double &rdq, double &rd1)
 {
     const int N = P.N, M = P.M, E = P.E, ldz = P.ldz, ldm = P.ldm, lde = P.lde, ldt = P.ldt;
     const double *Q = P.Q + (long long)qp * P.sQ;
@@ -307,44 +395,51 @@ __device__ int qp_setup(const KParams &P, const Lds &S, int qp, int lane, double
     return status;
 }
 
-// T = R + diag(dinv), then L D L^T.  dinv: element i on lane i.  Returns 1/D on lane i.
-__device__ __forceinline__ double factor_T(const KParams &P, const Lds &S, double dinv, int lane)
+// T = R + diag(dinv) loaded column-per-lane into registers, then L D L^T.  dinv: element i
+// on lane i.  Returns 1/D on lane i.
+template <int MAXM>
+__device__ __forceinline__ double factor_T(const KParams &P, const Lds &S, double (&t)[MAXM],
+                                           double dinv, int lane)
 {
-    const int M = P.M, ldm = P.ldm, ldt = P.ldt;
-    WSYNC();
-    for (int i = 0; i < M; ++i) {
-        const double di = bcast(dinv, i);
-        if (lane < M) S.T[i * ldt + lane] = S.R[i * ldm + lane] + (lane == i ? di : 0.0);
-    }
-    return ldl_factor(S.T, ldt, M, lane);
+    const int M = P.M, ldm = P.ldm;
+    const double *col = S.R + (lane < M ? lane : 0);   // R symmetric: column == row
+#pragma unroll
+    for (int i = 0; i < MAXM; ++i) t[i] = (i < M) ? col[i * ldm] : 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXM; ++i)
+        if (i < M && lane == i) t[i] += dinv;
+    return ldl_reg<MAXM>(t, M, lane);
 }
 
 // z-part of solve_kkt in hat coordinates: returns wz = dz.
 //   rxh (lane<N), rsd = rs/d (lane<M), rz (lane<M), ryt (lane<E)
-__device__ __forceinline__ double kkt_wz(const KParams &P, const Lds &S, double rdT, double rxh,
-                                         double rsd, double rz, double ryt, int lane)
+template <int MAXM>
+__device__ __forceinline__ double kkt_wz(const KParams &P, const Lds &S, const double (&t)[MAXM],
+                                         double rdT, double rxh, double rsd, double rz,
+                                         double ryt, int lane)
 {
     const int N = P.N, M = P.M, E = P.E;
     double u = rxh;
     if (E > 0) {
-        const double t = matvec(S.At, P.ldz, E, N, rxh, lane) - ryt;
-        u = rxh - matvecT(S.At, P.ldz, E, N, t, lane);
+        const double t = matvec<MAXM>(S.At, P.ldz, E, N, rxh, lane) - ryt;
+        u = rxh - matvecT<MAXM>(S.At, P.ldz, E, N, t, lane);
     }
-    const double g = rz - rsd - matvec(S.Gh, P.ldz, M, N, u, lane);
-    return ldl_solve(S.T, P.ldt, M, g, rdT, lane);
+    const double g = rz - rsd - matvec<MAXM>(S.Gh, P.ldz, M, N, u, lane);
+    return ldl_reg_solve<MAXM>(t, M, g, rdT, lane);
 }
 
 // x/y-part of solve_kkt for (the sum of) wz: dxh = -q + At^T(At q - ryt), dyt = -(At q - ryt)
+template <int MAXM>
 __device__ __forceinline__ void kkt_xy(const KParams &P, const Lds &S, double rxh, double ryt,
                                        double wz, int lane, double &dxh, double &dyt)
 {
     const int N = P.N, M = P.M, E = P.E;
-    const double q = rxh + matvecT(S.Gh, P.ldz, M, N, wz, lane);
+    const double q = rxh + matvecT<MAXM>(S.Gh, P.ldz, M, N, wz, lane);
     dxh = -q;
     dyt = 0.0;
     if (E > 0) {
-        const double e = matvec(S.At, P.ldz, E, N, q, lane) - ryt;
-        dxh += matvecT(S.At, P.ldz, E, N, e, lane);
+        const double e = matvec<MAXM>(S.At, P.ldz, E, N, q, lane) - ryt;
+        dxh += matvecT<MAXM>(S.At, P.ldz, E, N, e, lane);
         dyt = -e;
     }
 }
@@ -355,6 +450,7 @@ __device__ __forceinline__ double step_ratio(double v, double dv, bool active)
     return (active && dv < 0.0) ? -v / dv : INFINITY;
 }
 
+template <int MAXM>
 __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -373,11 +469,12 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
     if (E > 0) bt = trsv_L(S.L1, P.lde, E, bt, rd1, lane);
 
     // initial point: d = 1, solve_kkt(p, 0, -h, -b)                     batch.py:60-74
-    double rdT = factor_T(P, S, inM ? 1.0 : 0.0, lane);
+    double t[MAXM];
+    double rdT = factor_T<MAXM>(P, S, t, inM ? 1.0 : 0.0, lane);
     double xh, s, z, yt;
     {
-        const double wz = kkt_wz(P, S, rdT, ph, 0.0, -hh, -bt, lane);
-        kkt_xy(P, S, ph, -bt, wz, lane, xh, yt);
+        const double wz = kkt_wz<MAXM>(P, S, t, rdT, ph, 0.0, -hh, -bt, lane);
+        kkt_xy<MAXM>(P, S, ph, -bt, wz, lane, xh, yt);
         z = wz;
         s = -wz;
     }
@@ -393,17 +490,17 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
 
     for (int it = 0; it < P.maxIter; ++it) {
         // residuals in hat coordinates                                   batch.py:93-108
-        double rxh = xh + ph + matvecT(S.Gh, P.ldz, M, N, z, lane);
+        double rxh = xh + ph + matvecT<MAXM>(S.Gh, P.ldz, M, N, z, lane);
         double ryt = 0.0;
         if (E > 0) {
-            rxh += matvecT(S.At, P.ldz, E, N, yt, lane);
-            ryt = matvec(S.At, P.ldz, E, N, xh, lane) - bt;
+            rxh += matvecT<MAXM>(S.At, P.ldz, E, N, yt, lane);
+            ryt = matvec<MAXM>(S.At, P.ldz, E, N, xh, lane) - bt;
         }
-        const double gx = matvec(S.Gh, P.ldz, M, N, xh, lane);
+        const double gx = matvec<MAXM>(S.Gh, P.ldz, M, N, xh, lane);
         const double rz = inM ? gx + s - hh : 0.0;
-        const double rx = trimatvec(S.Lq, P.ldz, N, rxh, lane);       // rx = Lq rxh
+        const double rx = trimatvec<MAXM>(S.Lq, P.ldz, N, rxh, lane);       // rx = Lq rxh
         double ry = 0.0;
-        if (E > 0) ry = trimatvec(S.L1, P.lde, E, ryt, lane);
+        if (E > 0) ry = trimatvec<MAXM>(S.L1, P.lde, E, ryt, lane);
         const double sz = wave_sum(inM ? s * z : 0.0);
         const double mu = fabs(sz / M);
         const double resid = sqrt(wave_sum(rz * rz)) + sqrt(wave_sum(ry * ry)) +
@@ -422,10 +519,10 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
             break;
 
         const double dinv = inM ? s / z : 0.0;                          // 1/d, d = z/s
-        rdT = factor_T(P, S, dinv, lane);
+        rdT = factor_T<MAXM>(P, S, t, dinv, lane);
 
         // affine direction (rs = z  =>  rs/d = s)                        batch.py:151
-        const double dz_a = kkt_wz(P, S, rdT, rxh, s, rz, ryt, lane);
+        const double dz_a = kkt_wz<MAXM>(P, S, t, rdT, rxh, s, rz, ryt, lane);
         const double ds_a = inM ? (-z - dz_a) * dinv : 0.0;
         double alpha = fmin(wave_min(fmin(step_ratio(z, dz_a, inM), step_ratio(s, ds_a, inM))), 1.0);
         const double t3 = wave_sum(inM ? (s + alpha * ds_a) * (z + alpha * dz_a) : 0.0);
@@ -433,11 +530,11 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
         sig = sig * sig * sig;
         // corrector: rx = rz = ry = 0, rs = (-mu sig + ds_a dz_a)/s       batch.py:171-181
         const double rs_c = inM ? (-mu * sig + ds_a * dz_a) / s : 0.0;
-        const double dz_c = ldl_solve(S.T, P.ldt, M, -rs_c * dinv, rdT, lane);
+        const double dz_c = ldl_reg_solve<MAXM>(t, M, -rs_c * dinv, rdT, lane);
         const double ds_c = inM ? (-rs_c - dz_c) * dinv : 0.0;
         const double dz = dz_a + dz_c, ds = ds_a + ds_c;
         double dxh, dyt;
-        kkt_xy(P, S, rxh, ryt, dz, lane, dxh, dyt);
+        kkt_xy<MAXM>(P, S, rxh, ryt, dz, lane, dxh, dyt);
 
         alpha = fmin(0.999 * wave_min(fmin(step_ratio(z, dz, inM), step_ratio(s, ds, inM))), 1.0);
         xh += alpha * dxh;
@@ -464,6 +561,7 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
 }
 
 // QPFunctionFn.backward (qp.py:128-183) / DenseQPFunction Solver.backward (qp.py:239-270)
+template <int MAXM>
 __global__ __launch_bounds__(WAVE) void qp_backward_kernel(KParams P)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -484,13 +582,14 @@ __global__ __launch_bounds__(WAVE) void qp_backward_kernel(KParams P)
     double dinv;
     if (P.flags & DQP_FLAG_DENSE_BACKWARD) dinv = inM ? slk / lam : 0.0;
     else dinv = inM ? fmax(slk, 1e-8) / fmax(lam, 1e-8) : 0.0;       // qp.py:149
-    const double rdT = factor_T(P, S, dinv, lane);
+    double t[MAXM];
+    const double rdT = factor_T<MAXM>(P, S, t, dinv, lane);
 
     // solve_kkt(rx = dl_dzhat, 0, 0, 0)
     const double rxh = trsv_L(S.Lq, P.ldz, N, g, rdq, lane);
-    const double dlam = kkt_wz(P, S, rdT, rxh, 0.0, 0.0, 0.0, lane);
+    const double dlam = kkt_wz<MAXM>(P, S, t, rdT, rxh, 0.0, 0.0, 0.0, lane);
     double dxh, dyt;
-    kkt_xy(P, S, rxh, 0.0, dlam, lane, dxh, dyt);
+    kkt_xy<MAXM>(P, S, rxh, 0.0, dlam, lane, dxh, dyt);
     const double dx = trsv_LT(S.Lq, P.ldz, N, dxh, rdq, lane);
     double dnu = 0.0;
     if (E > 0) dnu = trsv_LT(S.L1, P.lde, E, dyt, rd1, lane);
@@ -596,7 +695,10 @@ dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, cons
     P.Q = Q; P.p = p; P.G = G; P.h = h; P.A = A; P.b = b;
     P.zhat = zhat; P.lam = lam; P.nu = nu; P.slack = slack;
     P.info = info; P.best_resid = best_resid;
-    return launch(qp_forward_kernel, P, lds, stream);
+    const int mx = P.N > P.M ? (P.N > P.E ? P.N : P.E) : (P.M > P.E ? P.M : P.E);
+    if (mx <= 16) return launch(qp_forward_kernel<16>, P, lds, stream);
+    if (mx <= 32) return launch(qp_forward_kernel<32>, P, lds, stream);
+    return launch(qp_forward_kernel<64>, P, lds, stream);
 }
 
 __attribute__((visibility("default"))) int
@@ -617,7 +719,10 @@ dqp_qp_backward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, con
     P.zin = zhat; P.lamin = lam; P.nuin = nu; P.slackin = slack; P.gin = dl_dzhat;
     P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db;
     P.info = info;
-    return launch(qp_backward_kernel, P, lds, stream);
+    const int mx = P.N > P.M ? (P.N > P.E ? P.N : P.E) : (P.M > P.E ? P.M : P.E);
+    if (mx <= 16) return launch(qp_backward_kernel<16>, P, lds, stream);
+    if (mx <= 32) return launch(qp_backward_kernel<32>, P, lds, stream);
+    return launch(qp_backward_kernel<64>, P, lds, stream);
 }
 
 }  // extern "C"
