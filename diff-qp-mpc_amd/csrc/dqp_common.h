@@ -1,0 +1,37 @@
+// dqp_common.h -- kernel parameter block shared by the HIP translation units of libdqp_hip.so
+#ifndef DQP_COMMON_H_
+#define DQP_COMMON_H_
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dqp.h"
+
+namespace dqp {
+
+constexpr int WAVE = 64;
+
+struct KParams {
+    const double *Q, *p, *G, *h, *A, *b;
+    long long sQ, sp, sG, sh, sA, sb;
+    // forward outputs
+    double *zhat, *lam, *nu, *slack, *best_resid;
+    // backward inputs / outputs
+    const double *zin, *lamin, *nuin, *slackin, *gin;
+    double *dQ, *dp, *dG, *dh, *dA, *db;
+    int32_t *info;
+    int B, N, M, E;
+    int ldz, ldm, lde, ldt;
+    double eps, stallTol;
+    int maxIter, notImprovedLim;
+    unsigned flags;
+};
+
+
+// DPP-row kernels (dqp_r16.hip): 4 QPs per wavefront for compile-time sizes <= 32.
+// Return DQP_OK / error, or 1 when no instantiation matches (caller falls back to the
+// generic kernels of dqp_pdipm.hip).
+int r16_forward(const KParams &P, void *stream);
+int r16_backward(const KParams &P, void *stream);
+
+}  // namespace dqp
+#endif

@@ -27,27 +27,11 @@
 #include <math.h>
 #include <stdint.h>
 
-#include "../../include/dqp.h"
+#include "dqp_common.h"
+
+using namespace dqp;
 
 namespace {
-
-constexpr int WAVE = 64;
-
-struct KParams {
-    const double *Q, *p, *G, *h, *A, *b;
-    long long sQ, sp, sG, sh, sA, sb;
-    // forward outputs
-    double *zhat, *lam, *nu, *slack, *best_resid;
-    // backward inputs / outputs
-    const double *zin, *lamin, *nuin, *slackin, *gin;
-    double *dQ, *dp, *dG, *dh, *dA, *db;
-    int32_t *info;
-    int B, N, M, E;
-    int ldz, ldm, lde, ldt;
-    double eps, stallTol;
-    int maxIter, notImprovedLim;
-    unsigned flags;
-};
 
 #define WSYNC() __syncthreads()
 
@@ -695,6 +679,10 @@ dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, cons
     P.Q = Q; P.p = p; P.G = G; P.h = h; P.A = A; P.b = b;
     P.zhat = zhat; P.lam = lam; P.nu = nu; P.slack = slack;
     P.info = info; P.best_resid = best_resid;
+    if (!(P.flags & DQP_FLAG_GENERIC_ONLY)) {
+        rc = r16_forward(P, stream);      // DPP-row kernels for the instantiated sizes
+        if (rc != 1) return rc;
+    }
     const int mx = P.N > P.M ? (P.N > P.E ? P.N : P.E) : (P.M > P.E ? P.M : P.E);
     if (mx <= 16) return launch(qp_forward_kernel<16>, P, lds, stream);
     if (mx <= 32) return launch(qp_forward_kernel<32>, P, lds, stream);
@@ -719,6 +707,10 @@ dqp_qp_backward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, con
     P.zin = zhat; P.lamin = lam; P.nuin = nu; P.slackin = slack; P.gin = dl_dzhat;
     P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db;
     P.info = info;
+    if (!(P.flags & DQP_FLAG_GENERIC_ONLY)) {
+        rc = r16_backward(P, stream);
+        if (rc != 1) return rc;
+    }
     const int mx = P.N > P.M ? (P.N > P.E ? P.N : P.E) : (P.M > P.E ? P.M : P.E);
     if (mx <= 16) return launch(qp_backward_kernel<16>, P, lds, stream);
     if (mx <= 32) return launch(qp_backward_kernel<32>, P, lds, stream);

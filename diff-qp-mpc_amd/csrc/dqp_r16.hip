@@ -1,0 +1,926 @@
+// dqp_r16.hip -- DPP-row kernels: FOUR QPs per wavefront, one per 16-lane DPP row.
+//
+// For problems with nz, nineq <= 32 and neq <= 16 (compile-time sizes) every matrix of the
+// interior-point iteration is held in REGISTERS, "row-distributed": row i of a matrix lives on
+// lane (i % 16) of the QP's DPP row, in slot (i / 16), with all of its columns in consecutive
+// VGPRs.  A vector is distributed the same way (element i on lane i%16, slot i/16).
+// The only cross-lane primitive is the CDNA DPP row broadcast (`v_mov_b64_dpp row_newbcast:k`,
+// full rate, no LDS, no SGPR round trip), so
+//   * y = M x       is   for j: y[s] += M[s][j] * bcast_j(x)            (no reduction)
+//   * LU / Cholesky / triangular solves are rank-1 updates with bcast of the pivot row/entry
+//   * y = M^T v     is a lane-local partial product + a 4-round mirror butterfly (reduce-scatter)
+// and four independent QPs advance in lock-step in the same instruction stream, which amortises
+// every latency-bound dependent chain (pivots, substitution steps) over four problems.
+// LDS only holds the per-QP constants that are touched once per iteration (packed lower
+// triangles of R, Lq, L1: 8.4 KB per QP for the metric size).
+//
+// Math: identical to dqp_pdipm.hip (see its header): hat coordinates xh = Lq^T x, orthonormal
+// equality rows At, T = R + diag(s/z) factored per iteration -- here as an unpivoted LU (what
+// the reference itself does on GPUs, batch.py:8-19), because row-distributed storage gives
+// the U rows needed for back-substitution for free.
+//
+// Reference functions covered: as dqp_pdipm.hip.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "dqp_common.h"
+
+namespace dqp {
+namespace r16 {
+
+// ------------------------------------------------------------------ cross-lane primitives
+template <int CTRL> __device__ __forceinline__ double dppd(double v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true);
+}
+
+// value of lane k (0..15) of each DPP row, in every lane of that row.  k folds to a constant
+// after unrolling, leaving a single v_mov_b64_dpp row_newbcast:k.
+__device__ __forceinline__ double rb(double v, int k)
+{
+    switch (k & 15) {
+    case 0: return dppd<0x150>(v);   case 1: return dppd<0x151>(v);
+    case 2: return dppd<0x152>(v);   case 3: return dppd<0x153>(v);
+    case 4: return dppd<0x154>(v);   case 5: return dppd<0x155>(v);
+    case 6: return dppd<0x156>(v);   case 7: return dppd<0x157>(v);
+    case 8: return dppd<0x158>(v);   case 9: return dppd<0x159>(v);
+    case 10: return dppd<0x15a>(v);  case 11: return dppd<0x15b>(v);
+    case 12: return dppd<0x15c>(v);  case 13: return dppd<0x15d>(v);
+    case 14: return dppd<0x15e>(v);  default: return dppd<0x15f>(v);
+    }
+}
+#define BC(vec, k) rb((vec)[(k) >> 4], (k) & 15)   /* element k of a distributed vector */
+
+__device__ __forceinline__ double row_sum(double v)
+{
+    v += dppd<0x128>(v); v += dppd<0x124>(v); v += dppd<0x122>(v); v += dppd<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ double row_min(double v)
+{
+    v = fmin(v, dppd<0x128>(v)); v = fmin(v, dppd<0x124>(v));
+    v = fmin(v, dppd<0x122>(v)); v = fmin(v, dppd<0x121>(v));
+    return v;
+}
+
+// full-precision reciprocal / reciprocal square root from the hardware estimates + 2 Newton steps
+__device__ __forceinline__ double frcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double frsqrt(double d)
+{
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    y = y * fma(-0.5 * d * y, y, 1.5);
+    return y;
+}
+
+constexpr __host__ __device__ int slots(int n) { return (n + 15) / 16; }
+constexpr __host__ __device__ int tri(int i) { return i * (i + 1) / 2; }
+
+// ------------------------------------------------------------------ mat-vec building blocks
+// y[s] (+)= sum_j M[s][j] * x_j          (M row-distributed SR x NC, x distributed length NC)
+template <int SR, int NC, int SX>
+__device__ __forceinline__ void mv_nat(const double (&Mx)[SR][NC], const double (&x)[SX],
+                                       double (&y)[SR], bool accumulate)
+{
+    if (!accumulate) {
+#pragma unroll
+        for (int s = 0; s < SR; ++s) y[s] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < NC; ++j) {
+        const double xb = BC(x, j);
+#pragma unroll
+        for (int s = 0; s < SR; ++s) y[s] = fma(Mx[s][j], xb, y[s]);
+    }
+}
+
+// Reduce-scatter over the 16 lanes of a DPP row: on entry every lane holds its partial p[c] of
+// NC column sums; on exit y[c >> 4] on lane (c & 15) holds the total of column c.  Four mirror
+// butterflies (row_mirror, row_half_mirror, quad reverse, quad swap) halve the live values.
+template <int NC, int SY>
+__device__ __forceinline__ void reduce_scatter(double (&p)[NC], double (&y)[SY], int r)
+{
+    const bool h8 = (r & 8) != 0, h4 = (r & 4) != 0, h2 = (r & 2) != 0, h1 = (r & 1) != 0;
+#pragma unroll
+    for (int g = 0; g < SY; ++g) {
+        double a[8], b4[4], c2[2];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double lo = (16 * g + k < NC) ? p[16 * g + k] : 0.0;
+            const double hi = (16 * g + k + 8 < NC) ? p[(16 * g + k + 8 < NC) ? 16 * g + k + 8 : 0] : 0.0;
+            const double keep = h8 ? hi : lo, send = h8 ? lo : hi;
+            a[k] = keep + dppd<0x140>(send);                 // row_mirror: l <-> 15-l
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double keep = h4 ? a[k + 4] : a[k], send = h4 ? a[k] : a[k + 4];
+            b4[k] = keep + dppd<0x141>(send);                // row_half_mirror: l <-> 7-l
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const double keep = h2 ? b4[k + 2] : b4[k], send = h2 ? b4[k] : b4[k + 2];
+            c2[k] = keep + dppd<0x1b>(send);                 // quad_perm [3,2,1,0]
+        }
+        const double keep = h1 ? c2[1] : c2[0], send = h1 ? c2[0] : c2[1];
+        y[g] = keep + dppd<0xb1>(send);                      // quad_perm [1,0,3,2]
+    }
+}
+
+// y = M^T v   (M row-distributed SR x NC, v distributed over the rows; y distributed length NC)
+template <int SR, int NC, int SY>
+__device__ __forceinline__ void mv_tr(const double (&Mx)[SR][NC], const double (&v)[SR],
+                                      double (&y)[SY], int r)
+{
+    double p[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        double a = Mx[0][c] * v[0];
+#pragma unroll
+        for (int s = 1; s < SR; ++s) a = fma(Mx[s][c], v[s], a);
+        p[c] = a;
+    }
+    reduce_scatter<NC, SY>(p, y, r);
+}
+
+// ------------------------------------------------------------------ factorizations in registers
+// Lower Cholesky of the row-distributed SPD matrix (in place; strict upper part zeroed).
+// rd[s] = 1/L[i][i] for the lane's rows.  Returns false on a non-positive pivot.
+template <int S, int N>
+__device__ __forceinline__ bool chol_rows(double (&L)[S][N], double (&rd)[S], int r)
+{
+    bool ok = true;
+#pragma unroll
+    for (int s = 0; s < S; ++s) rd[s] = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int sk = k >> 4, lk = k & 15;
+        double dk = rb(L[sk][k], lk);
+        if (!(dk > 0.0)) { ok = false; dk = 1.0; }
+        const double ri = frsqrt(dk);
+        if (r == lk) rd[sk] = ri;
+        double col[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (16 * s + 15 < k) col[s] = 0.0;                              // rows all above k
+            else if (16 * s >= k) col[s] = L[s][k] * ri;                    // rows all >= k
+            else col[s] = (r >= lk) ? L[s][k] * ri : 0.0;
+            L[s][k] = col[s];
+        }
+#pragma unroll
+        for (int j = k + 1; j < N; ++j) {
+            const double cj = BC(col, j);
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (16 * s + 15 >= j) L[s][j] = fma(-col[s], cj, L[s][j]);   // only rows i >= j matter
+        }
+    }
+    return ok;
+}
+
+// Unpivoted LU of the row-distributed matrix (in place: unit-lower multipliers below the
+// diagonal, U on/above).  rdu[s] = 1/U[i][i].
+template <int S, int N>
+__device__ __forceinline__ void lu_rows(double (&T)[S][N], double (&rdu)[S], int r)
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s) rdu[s] = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int sk = k >> 4, lk = k & 15;
+        const double rp = frcp(rb(T[sk][k], lk));
+        if (r == lk) rdu[sk] = rp;
+        double l[S];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (16 * s + 15 <= k) l[s] = 0.0;
+            else if (16 * s > k) { l[s] = T[s][k] * rp; T[s][k] = l[s]; }
+            else { const bool a = r > lk; l[s] = a ? T[s][k] * rp : 0.0; T[s][k] = a ? l[s] : T[s][k]; }
+        }
+#pragma unroll
+        for (int j = k + 1; j < N; ++j) {
+            const double ub = rb(T[sk][j], lk);
+#pragma unroll
+            for (int s = 0; s < S; ++s)
+                if (16 * s + 15 > k) T[s][j] = fma(-l[s], ub, T[s][j]);
+        }
+    }
+}
+
+// b <- T^-1 b with the LU above.
+template <int S, int N>
+__device__ __forceinline__ void lu_solve(const double (&T)[S][N], const double (&rdu)[S],
+                                         double (&b)[S], int r)
+{
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {                  // L y = b
+        const int lk = k & 15;
+        const double bk = BC(b, k);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (16 * s + 15 <= k) continue;
+            if (16 * s > k) b[s] = fma(-T[s][k], bk, b[s]);
+            else b[s] = fma(r > lk ? -T[s][k] : 0.0, bk, b[s]);
+        }
+    }
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {                 // U x = y
+        const int sk = k >> 4, lk = k & 15;
+        const double xk = rb(b[sk] * rdu[sk], lk);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (16 * s > k) continue;
+            if (16 * s + 15 < k) b[s] = fma(-T[s][k], xk, b[s]);
+            else b[s] = (r == lk) ? xk : fma(r < lk ? -T[s][k] : 0.0, xk, b[s]);
+        }
+    }
+}
+
+// b <- L^-1 b, L lower triangular row-distributed in registers (rd = reciprocal diagonal)
+template <int S, int N>
+__device__ __forceinline__ void trsv_rows(const double (&L)[S][N], const double (&rd)[S],
+                                          double (&b)[S], int r)
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int sk = k >> 4, lk = k & 15;
+        const double yk = rb(b[sk] * rd[sk], lk);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (16 * s + 15 < k) continue;
+            if (16 * s > k) b[s] = fma(-L[s][k], yk, b[s]);
+            else b[s] = (r == lk) ? yk : fma(r > lk ? -L[s][k] : 0.0, yk, b[s]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ packed-triangle LDS helpers
+// LDS holds, per QP, the packed lower triangle P[tri(i) + j], j <= i.
+template <int S, int N>
+__device__ __forceinline__ void tri_store(double *P, const double (&L)[S][N], int r)
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = r + 16 * s;
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (j <= 16 * s + 15 && i < N && j <= i) P[tri(i) + j] = L[s][j];
+    }
+}
+
+// y = L x with L the packed lower triangle in LDS (x, y distributed length N)
+template <int S, int N>
+__device__ __forceinline__ void tri_mv(const double *P, const double (&x)[S], double (&y)[S], int r)
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s) y[s] = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double xb = BC(x, j);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (16 * s + 15 < j) continue;
+            const int i = r + 16 * s;
+            const int ic = i < N ? i : N - 1;
+            const double v = P[tri(ic) + (j <= ic ? j : 0)];
+            y[s] = fma((j <= i && i < N) ? v : 0.0, xb, y[s]);
+        }
+    }
+}
+
+// b <- L^-1 b with L packed in LDS (forward substitution; rd distributed reciprocal diagonal)
+template <int S, int N>
+__device__ __forceinline__ void tri_solve(const double *P, const double (&rd)[S], double (&b)[S], int r)
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const int sk = k >> 4, lk = k & 15;
+        const double yk = rb(b[sk] * rd[sk], lk);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (16 * s + 15 < k) continue;
+            const int i = r + 16 * s;
+            const int ic = i < N ? i : N - 1;
+            const double v = P[tri(ic) + (k <= ic ? k : 0)];
+            if (16 * s > k) b[s] = fma((i < N) ? -v : 0.0, yk, b[s]);
+            else b[s] = (r == lk) ? yk : fma((r > lk && i < N) ? -v : 0.0, yk, b[s]);
+        }
+    }
+}
+
+// b <- L^-T b with L packed in LDS: x_j = (b_j - sum_{i>j} L[i][j] x_i) / L[j][j]; the sum over
+// rows is a row reduction (the transposed access pattern of row-distributed storage).
+template <int S, int N>
+__device__ __forceinline__ void tri_solve_T(const double *P, const double (&rd)[S], double (&b)[S], int r)
+{
+#pragma unroll
+    for (int j = N - 1; j >= 0; --j) {
+        const int sj = j >> 4, lj = j & 15;
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (16 * s + 15 <= j) continue;
+            const int i = r + 16 * s;
+            const int ic = i < N ? i : N - 1;
+            const double v = P[tri(ic) + (j <= ic ? j : 0)];
+            part = fma((i > j && i < N) ? v : 0.0, b[s], part);
+        }
+        const double tot = row_sum(part);
+        if (r == lj) b[sj] = (b[sj] - tot) * rd[sj];
+    }
+}
+
+// ------------------------------------------------------------------ per-size configuration
+template <int N_, int M_, int E_> struct Cfg {
+    static constexpr int N = N_, M = M_, E = E_;
+    static constexpr int SN = slots(N_), SM = slots(M_), SE = E_ > 0 ? slots(E_) : 1;
+    static constexpr int EC = E_ > 0 ? E_ : 1;            // column count for E-sized arrays
+    // packed triangles in LDS, per QP (doubles)
+    static constexpr int oR = 0, oLq = tri(M_), oL1 = tri(M_) + tri(N_);
+    static constexpr int ldsQP = tri(M_) + tri(N_) + tri(E_) + 1;
+    static constexpr int ldsQPpad = (ldsQP + 1) & ~1;
+};
+
+// Everything the iteration needs, produced by setup():
+template <class C> struct State {
+    double Gh[C::SM][C::N];      // Gh = G Lq^-T
+    double Ah[C::SE][C::N];      // At = L1^-1 A Lq^-T (orthonormal rows)
+    double rdq[C::SN];           // 1 / diag(Lq)
+    double rd1[C::SE];           // 1 / diag(L1)
+    int status;
+};
+
+// One-time factorisations (reference: pre_factor_kkt, batch.py:377-428), all in registers.
+// Writes packed R, Lq, L1 to this QP's LDS block.
+template <class C>
+__device__ __forceinline__ void setup(const KParams &P, long long qp, int r, double *lds, State<C> &st)
+{
+    constexpr int N = C::N, M = C::M, E = C::E, SN = C::SN, SM = C::SM, SE = C::SE;
+    st.status = DQP_STATUS_OK;
+    {
+        double Lq[SN][N];
+        const double *Q = P.Q + qp * P.sQ;
+#pragma unroll
+        for (int s = 0; s < SN; ++s) {
+            const int i = r + 16 * s;
+            const double *row = Q + (i < N ? i : 0) * N;
+#pragma unroll
+            for (int j = 0; j < N; ++j) Lq[s][j] = (i < N) ? row[j] : (i == j ? 1.0 : 0.0);
+        }
+        // pad rows (i >= N) do not exist for j < N, so the "identity" padding never triggers;
+        // pad rows simply stay zero and are masked wherever a pivot would be read.
+        if (!chol_rows<SN, N>(Lq, st.rdq, r)) st.status = DQP_STATUS_Q_NOT_PD;
+
+        // rows of G and A:  row <- row Lq^-T   (row[j] = (row[j] - sum_{k<j} row[k] Lq[j][k]) / Lq[j][j])
+        const double *G = P.G + qp * P.sG;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            const int i = r + 16 * s;
+            const double *row = G + (i < M ? i : 0) * N;
+#pragma unroll
+            for (int j = 0; j < N; ++j) st.Gh[s][j] = (i < M) ? row[j] : 0.0;
+        }
+        if (E > 0) {
+            const double *A = P.A + qp * P.sA;
+#pragma unroll
+            for (int s = 0; s < SE; ++s) {
+                const int i = r + 16 * s;
+                const double *row = A + (i < E ? i : 0) * N;
+#pragma unroll
+                for (int j = 0; j < N; ++j) st.Ah[s][j] = (i < E) ? row[j] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int sj = j >> 4, lj = j & 15;
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                const double ljk = rb(Lq[sj][k], lj);
+#pragma unroll
+                for (int s = 0; s < SM; ++s) st.Gh[s][j] = fma(-st.Gh[s][k], ljk, st.Gh[s][j]);
+                if (E > 0) {
+#pragma unroll
+                    for (int s = 0; s < SE; ++s) st.Ah[s][j] = fma(-st.Ah[s][k], ljk, st.Ah[s][j]);
+                }
+            }
+            const double rj = rb(st.rdq[sj], lj);
+#pragma unroll
+            for (int s = 0; s < SM; ++s) st.Gh[s][j] *= rj;
+            if (E > 0) {
+#pragma unroll
+                for (int s = 0; s < SE; ++s) st.Ah[s][j] *= rj;
+            }
+        }
+        tri_store<SN, N>(lds + C::oLq, Lq, r);
+    }
+
+    if (E > 0) {
+        constexpr int EC = C::EC;
+        double L1[SE][EC];
+        // S11 = Ah Ah^T
+#pragma unroll
+        for (int j = 0; j < EC; ++j) {
+            const int sj = j >> 4, lj = j & 15;
+#pragma unroll
+            for (int s = 0; s < SE; ++s) L1[s][j] = 0.0;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const double ab = rb(st.Ah[sj][c], lj);
+#pragma unroll
+                for (int s = 0; s < SE; ++s) L1[s][j] = fma(st.Ah[s][c], ab, L1[s][j]);
+            }
+        }
+        if (!chol_rows<SE, EC>(L1, st.rd1, r) && st.status == DQP_STATUS_OK)
+            st.status = DQP_STATUS_A_RANK_DEF;
+        // At = L1^-1 Ah: eliminate with unscaled rows, scale once at the end
+#pragma unroll
+        for (int g = 0; g < EC; ++g) {
+            const int sg = g >> 4, lg = g & 15;
+            const double rg = rb(st.rd1[sg], lg);
+            double m[SE];
+#pragma unroll
+            for (int s = 0; s < SE; ++s) {
+                if (16 * s + 15 <= g) m[s] = 0.0;
+                else if (16 * s > g) m[s] = L1[s][g] * rg;
+                else m[s] = (r > lg) ? L1[s][g] * rg : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const double ub = rb(st.Ah[sg][c], lg);
+#pragma unroll
+                for (int s = 0; s < SE; ++s)
+                    if (16 * s + 15 > g) st.Ah[s][c] = fma(-m[s], ub, st.Ah[s][c]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SE; ++s)
+#pragma unroll
+            for (int c = 0; c < N; ++c) st.Ah[s][c] *= st.rd1[s];
+        tri_store<SE, EC>(lds + C::oL1, L1, r);
+    } else {
+#pragma unroll
+        for (int s = 0; s < SE; ++s) st.rd1[s] = 0.0;
+    }
+
+    {   // Gbar = Gh - (Gh At^T) At ;  R = Gbar Gbar^T (packed lower triangle -> LDS)
+        double Gb[SM][N];
+#pragma unroll
+        for (int s = 0; s < SM; ++s)
+#pragma unroll
+            for (int c = 0; c < N; ++c) Gb[s][c] = st.Gh[s][c];
+        if (E > 0) {
+#pragma unroll
+            for (int e = 0; e < C::EC; ++e) {
+                const int se = e >> 4, le = e & 15;
+                double w[SM];
+#pragma unroll
+                for (int s = 0; s < SM; ++s) w[s] = 0.0;
+#pragma unroll
+                for (int c = 0; c < N; ++c) {
+                    const double ab = rb(st.Ah[se][c], le);
+#pragma unroll
+                    for (int s = 0; s < SM; ++s) w[s] = fma(st.Gh[s][c], ab, w[s]);
+                }
+#pragma unroll
+                for (int c = 0; c < N; ++c) {
+                    const double ab = rb(st.Ah[se][c], le);
+#pragma unroll
+                    for (int s = 0; s < SM; ++s) Gb[s][c] = fma(-w[s], ab, Gb[s][c]);
+                }
+            }
+        }
+        double *Rp = lds + C::oR;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            const int sj = j >> 4, lj = j & 15;
+            double acc[SM];
+#pragma unroll
+            for (int s = 0; s < SM; ++s) acc[s] = 0.0;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const double gb = rb(Gb[sj][c], lj);
+#pragma unroll
+                for (int s = 0; s < SM; ++s)
+                    if (16 * s + 15 >= j) acc[s] = fma(Gb[s][c], gb, acc[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < SM; ++s) {
+                const int i = r + 16 * s;
+                if (16 * s + 15 >= j && i < M && j <= i) Rp[tri(i) + j] = acc[s];
+            }
+        }
+    }
+    __syncthreads();   // factor_T reads R[j][i] written by the lane that owns row j
+}
+
+// T = R + diag(dinv) (full square, row-distributed) from the packed triangle in LDS, then LU.
+template <class C>
+__device__ __forceinline__ void factor_T(const double *lds, double (&T)[C::SM][C::M],
+                                         const double (&dinv)[C::SM], double (&rdu)[C::SM], int r)
+{
+    constexpr int M = C::M, SM = C::SM;
+    const double *Rp = lds + C::oR;
+#pragma unroll
+    for (int s = 0; s < SM; ++s) {
+        const int i = r + 16 * s;
+        const int ic = i < M ? i : M - 1;
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            int off;
+            if (16 * s > j) off = tri(ic) + j;                          // all rows below column j
+            else if (16 * s + 15 < j) off = tri(j) + ic;                // all rows above
+            else off = (j <= ic) ? tri(ic) + j : tri(j) + ic;
+            double v = Rp[off];
+            if (i >= M) v = (i == j) ? 1.0 : 0.0;
+            T[s][j] = (i == j) ? v + dinv[s] : v;
+        }
+    }
+    lu_rows<SM, M>(T, rdu, r);
+}
+
+// z-part of solve_kkt in hat coordinates (see dqp_pdipm.hip kkt_wz): returns wz in g.
+template <class C>
+__device__ __forceinline__ void kkt_wz(const State<C> &st, const double (&T)[C::SM][C::M],
+                                       const double (&rdu)[C::SM], const double (&rxh)[C::SN],
+                                       const double (&rsd)[C::SM], const double (&rz)[C::SM],
+                                       const double (&ryt)[C::SE], double (&wz)[C::SM], int r)
+{
+    double u[C::SN];
+#pragma unroll
+    for (int s = 0; s < C::SN; ++s) u[s] = rxh[s];
+    if (C::E > 0) {
+        double t[C::SE], at[C::SN];
+        mv_nat<C::SE, C::N, C::SN>(st.Ah, rxh, t, false);
+#pragma unroll
+        for (int s = 0; s < C::SE; ++s) t[s] -= ryt[s];
+        mv_tr<C::SE, C::N, C::SN>(st.Ah, t, at, r);
+#pragma unroll
+        for (int s = 0; s < C::SN; ++s) u[s] -= at[s];
+    }
+    double gu[C::SM];
+    mv_nat<C::SM, C::N, C::SN>(st.Gh, u, gu, false);
+#pragma unroll
+    for (int s = 0; s < C::SM; ++s) wz[s] = rz[s] - rsd[s] - gu[s];
+    lu_solve<C::SM, C::M>(T, rdu, wz, r);
+}
+
+// x/y-part: dxh = -q + At^T (At q - ryt), dyt = -(At q - ryt), q = rxh + Gh^T wz
+template <class C>
+__device__ __forceinline__ void kkt_xy(const State<C> &st, const double (&rxh)[C::SN],
+                                       const double (&ryt)[C::SE], const double (&wz)[C::SM],
+                                       double (&dxh)[C::SN], double (&dyt)[C::SE], int r)
+{
+    double q[C::SN];
+    mv_tr<C::SM, C::N, C::SN>(st.Gh, wz, q, r);
+#pragma unroll
+    for (int s = 0; s < C::SN; ++s) { q[s] += rxh[s]; dxh[s] = -q[s]; }
+#pragma unroll
+    for (int s = 0; s < C::SE; ++s) dyt[s] = 0.0;
+    if (C::E > 0) {
+        double e[C::SE], at[C::SN];
+        mv_nat<C::SE, C::N, C::SN>(st.Ah, q, e, false);
+#pragma unroll
+        for (int s = 0; s < C::SE; ++s) { e[s] -= ryt[s]; dyt[s] = -e[s]; }
+        mv_tr<C::SE, C::N, C::SN>(st.Ah, e, at, r);
+#pragma unroll
+        for (int s = 0; s < C::SN; ++s) dxh[s] += at[s];
+    }
+}
+
+__device__ __forceinline__ double ratio(double v, double dv, bool active)
+{
+    return (active && dv < 0.0) ? -v / dv : INFINITY;
+}
+
+template <class C>
+__global__ __launch_bounds__(64) void forward_kernel(KParams P)
+{
+    constexpr int N = C::N, M = C::M, E = C::E, SN = C::SN, SM = C::SM, SE = C::SE;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
+    long long qp = (long long)blockIdx.x * 4 + qrow;
+    const bool live = qp < P.B;
+    if (!live) qp = P.B - 1;                     // duplicate the last QP; its stores are masked
+    double *lds = sm + qrow * C::ldsQPpad;
+
+    State<C> st;
+    setup<C>(P, qp, r, lds, st);
+
+    bool inN[SN], inM[SM], inE[SE];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) inN[s] = r + 16 * s < N;
+#pragma unroll
+    for (int s = 0; s < SM; ++s) inM[s] = r + 16 * s < M;
+#pragma unroll
+    for (int s = 0; s < SE; ++s) inE[s] = r + 16 * s < E;
+
+    double ph[SN], hh[SM], bt[SE];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) ph[s] = inN[s] ? P.p[qp * P.sp + r + 16 * s] : 0.0;
+#pragma unroll
+    for (int s = 0; s < SM; ++s) hh[s] = inM[s] ? P.h[qp * P.sh + r + 16 * s] : 0.0;
+#pragma unroll
+    for (int s = 0; s < SE; ++s) bt[s] = (E > 0 && inE[s]) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
+    tri_solve<SN, N>(lds + C::oLq, st.rdq, ph, r);
+    if (E > 0) tri_solve<SE, C::EC>(lds + C::oL1, st.rd1, bt, r);
+
+    double T[SM][M], rdu[SM];
+    double xh[SN], s_[SM], z[SM], yt[SE];
+    {   // initial point: d = 1, solve_kkt(p, 0, -h, -b)                    batch.py:60-74
+        double one[SM], zero[SM], mh[SM], mb[SE], wz[SM];
+#pragma unroll
+        for (int s = 0; s < SM; ++s) { one[s] = inM[s] ? 1.0 : 0.0; zero[s] = 0.0; mh[s] = -hh[s]; }
+#pragma unroll
+        for (int s = 0; s < SE; ++s) mb[s] = -bt[s];
+        factor_T<C>(lds, T, one, rdu, r);
+        kkt_wz<C>(st, T, rdu, ph, zero, mh, mb, wz, r);
+        kkt_xy<C>(st, ph, mb, wz, xh, yt, r);
+        double ms = INFINITY, mz = INFINITY;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            z[s] = inM[s] ? wz[s] : 0.0;
+            s_[s] = inM[s] ? -wz[s] : 0.0;
+            ms = fmin(ms, inM[s] ? s_[s] : INFINITY);
+            mz = fmin(mz, inM[s] ? z[s] : INFINITY);
+        }
+        ms = row_min(ms); mz = row_min(mz);                                 // batch.py:76-86
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            if (ms < 0.0 && inM[s]) s_[s] -= ms - 1.0;
+            if (mz < 0.0 && inM[s]) z[s] -= mz - 1.0;
+        }
+    }
+
+    double bxh[SN], bs[SM], bz[SM], byt[SE], best = INFINITY;
+#pragma unroll
+    for (int s = 0; s < SN; ++s) bxh[s] = xh[s];
+#pragma unroll
+    for (int s = 0; s < SM; ++s) { bs[s] = s_[s]; bz[s] = z[s]; }
+#pragma unroll
+    for (int s = 0; s < SE; ++s) byt[s] = yt[s];
+    bool have_best = false, done = false;
+    int nNot = 0, iters = 0;
+
+    for (int it = 0; it < P.maxIter; ++it) {
+        // residuals in hat coordinates                                    batch.py:93-108
+        double rxh[SN], ryt[SE], rz[SM], tmpN[SN];
+        mv_tr<SM, N, SN>(st.Gh, z, rxh, r);
+#pragma unroll
+        for (int s = 0; s < SN; ++s) rxh[s] += xh[s] + ph[s];
+#pragma unroll
+        for (int s = 0; s < SE; ++s) ryt[s] = 0.0;
+        if (E > 0) {
+            mv_tr<SE, N, SN>(st.Ah, yt, tmpN, r);
+#pragma unroll
+            for (int s = 0; s < SN; ++s) rxh[s] += tmpN[s];
+            mv_nat<SE, N, SN>(st.Ah, xh, ryt, false);
+#pragma unroll
+            for (int s = 0; s < SE; ++s) ryt[s] -= bt[s];
+        }
+        mv_nat<SM, N, SN>(st.Gh, xh, rz, false);
+        double sz = 0.0, nz2 = 0.0, nx2 = 0.0, ny2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            rz[s] = inM[s] ? rz[s] + s_[s] - hh[s] : 0.0;
+            sz = fma(s_[s], z[s], sz);
+            nz2 = fma(rz[s], rz[s], nz2);
+        }
+        {
+            double rx[SN];
+            tri_mv<SN, N>(lds + C::oLq, rxh, rx, r);                        // rx = Lq rxh
+#pragma unroll
+            for (int s = 0; s < SN; ++s) nx2 = fma(rx[s], rx[s], nx2);
+            if (E > 0) {
+                double ry[SE];
+                tri_mv<SE, C::EC>(lds + C::oL1, ryt, ry, r);
+#pragma unroll
+                for (int s = 0; s < SE; ++s) ny2 = fma(ry[s], ry[s], ny2);
+            }
+        }
+        sz = row_sum(sz); nz2 = row_sum(nz2); nx2 = row_sum(nx2); ny2 = row_sum(ny2);
+        const double mu = fabs(sz / M);
+        const double resid = sqrt(nz2) + sqrt(ny2) + sqrt(nx2) + M * mu;
+        // best-iterate tracking / per-problem termination (uniform inside a DPP row)
+        if (!done) {
+            iters = it + 1;
+            if (!have_best || resid < best) {
+                nNot = 0; have_best = true; best = resid;
+#pragma unroll
+                for (int s = 0; s < SN; ++s) bxh[s] = xh[s];
+#pragma unroll
+                for (int s = 0; s < SM; ++s) { bs[s] = s_[s]; bz[s] = z[s]; }
+#pragma unroll
+                for (int s = 0; s < SE; ++s) byt[s] = yt[s];
+            } else {
+                nNot += 1;
+            }
+            if ((nNot >= P.notImprovedLim && best < P.stallTol) || best < P.eps || mu > 1e32 ||
+                !(fabs(resid) < INFINITY))
+                done = true;
+        }
+        // the wave leaves when all four of its QPs are done
+        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+
+        double dinv[SM];
+#pragma unroll
+        for (int s = 0; s < SM; ++s) dinv[s] = inM[s] ? s_[s] / z[s] : 0.0;   // 1/d, d = z/s
+        factor_T<C>(lds, T, dinv, rdu, r);
+
+        // affine direction (rs = z => rs/d = s)                             batch.py:151
+        double dza[SM], dsa[SM];
+        kkt_wz<C>(st, T, rdu, rxh, s_, rz, ryt, dza, r);
+        double am = INFINITY;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            dsa[s] = inM[s] ? (-z[s] - dza[s]) * dinv[s] : 0.0;
+            am = fmin(am, fmin(ratio(z[s], dza[s], inM[s]), ratio(s_[s], dsa[s], inM[s])));
+        }
+        double alpha = fmin(row_min(am), 1.0);
+        double t3 = 0.0;
+#pragma unroll
+        for (int s = 0; s < SM; ++s)
+            t3 += inM[s] ? (s_[s] + alpha * dsa[s]) * (z[s] + alpha * dza[s]) : 0.0;
+        t3 = row_sum(t3);
+        double sig = t3 / sz;
+        sig = sig * sig * sig;
+        // corrector: rx = rz = ry = 0, rs = (-mu sig + ds_a dz_a)/s            batch.py:171-181
+        double rsc[SM], dzc[SM], dz[SM], ds[SM];
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            rsc[s] = inM[s] ? (-mu * sig + dsa[s] * dza[s]) / s_[s] : 0.0;
+            dzc[s] = -rsc[s] * dinv[s];
+        }
+        lu_solve<SM, M>(T, rdu, dzc, r);
+        am = INFINITY;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            dz[s] = dza[s] + dzc[s];
+            ds[s] = dsa[s] + (inM[s] ? (-rsc[s] - dzc[s]) * dinv[s] : 0.0);
+            am = fmin(am, fmin(ratio(z[s], dz[s], inM[s]), ratio(s_[s], ds[s], inM[s])));
+        }
+        double dxh[SN], dyt[SE];
+        kkt_xy<C>(st, rxh, ryt, dz, dxh, dyt, r);
+        alpha = fmin(0.999 * row_min(am), 1.0);
+        if (!done) {
+#pragma unroll
+            for (int s = 0; s < SN; ++s) xh[s] = fma(alpha, dxh[s], xh[s]);
+#pragma unroll
+            for (int s = 0; s < SM; ++s) { s_[s] = fma(alpha, ds[s], s_[s]); z[s] = fma(alpha, dz[s], z[s]); }
+#pragma unroll
+            for (int s = 0; s < SE; ++s) yt[s] = fma(alpha, dyt[s], yt[s]);
+        }
+    }
+
+    // back to the caller's coordinates: x = Lq^-T xh, y = L1^-T yt
+    tri_solve_T<SN, N>(lds + C::oLq, st.rdq, bxh, r);
+    if (E > 0) tri_solve_T<SE, C::EC>(lds + C::oL1, st.rd1, byt, r);
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < SN; ++s)
+            if (inN[s]) P.zhat[qp * N + r + 16 * s] = bxh[s];
+#pragma unroll
+        for (int s = 0; s < SM; ++s)
+            if (inM[s]) { P.lam[qp * M + r + 16 * s] = bz[s]; P.slack[qp * M + r + 16 * s] = bs[s]; }
+        if (E > 0) {
+#pragma unroll
+            for (int s = 0; s < SE; ++s)
+                if (inE[s]) P.nu[qp * E + r + 16 * s] = byt[s];
+        }
+        if (r == 0) {
+            if (P.info) { P.info[2 * qp] = st.status; P.info[2 * qp + 1] = iters; }
+            if (P.best_resid) P.best_resid[qp] = best;
+        }
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(64) void backward_kernel(KParams P)
+{
+    constexpr int N = C::N, M = C::M, E = C::E, SN = C::SN, SM = C::SM, SE = C::SE;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
+    long long qp = (long long)blockIdx.x * 4 + qrow;
+    const bool live = qp < P.B;
+    if (!live) qp = P.B - 1;
+    double *lds = sm + qrow * C::ldsQPpad;
+
+    State<C> st;
+    setup<C>(P, qp, r, lds, st);
+
+    bool inN[SN], inM[SM], inE[SE];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) inN[s] = r + 16 * s < N;
+#pragma unroll
+    for (int s = 0; s < SM; ++s) inM[s] = r + 16 * s < M;
+#pragma unroll
+    for (int s = 0; s < SE; ++s) inE[s] = r + 16 * s < E;
+
+    double zh[SN], g[SN], lam[SM], dinv[SM], nu[SE];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) {
+        zh[s] = inN[s] ? P.zin[qp * N + r + 16 * s] : 0.0;
+        g[s] = inN[s] ? P.gin[qp * N + r + 16 * s] : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < SM; ++s) {
+        lam[s] = inM[s] ? P.lamin[qp * M + r + 16 * s] : 0.0;
+        const double sl = inM[s] ? P.slackin[qp * M + r + 16 * s] : 1.0;
+        if (P.flags & DQP_FLAG_DENSE_BACKWARD) dinv[s] = inM[s] ? sl / lam[s] : 0.0;
+        else dinv[s] = inM[s] ? fmax(sl, 1e-8) / fmax(lam[s], 1e-8) : 0.0;     // qp.py:149
+    }
+#pragma unroll
+    for (int s = 0; s < SE; ++s) nu[s] = (E > 0 && inE[s]) ? P.nuin[qp * E + r + 16 * s] : 0.0;
+
+    double T[SM][M], rdu[SM];
+    factor_T<C>(lds, T, dinv, rdu, r);
+    // solve_kkt(rx = dl_dzhat, 0, 0, 0)
+    tri_solve<SN, N>(lds + C::oLq, st.rdq, g, r);                       // rxh = Lq^-1 g
+    double zeroM[SM], zeroE[SE], dlam[SM], dxh[SN], dyt[SE];
+#pragma unroll
+    for (int s = 0; s < SM; ++s) zeroM[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < SE; ++s) zeroE[s] = 0.0;
+    kkt_wz<C>(st, T, rdu, g, zeroM, zeroM, zeroE, dlam, r);
+    kkt_xy<C>(st, g, zeroE, dlam, dxh, dyt, r);
+    tri_solve_T<SN, N>(lds + C::oLq, st.rdq, dxh, r);                   // dx = Lq^-T dxh
+    if (E > 0) tri_solve_T<SE, C::EC>(lds + C::oL1, st.rd1, dyt, r);    // dnu
+
+    if (!live) return;
+    // gradients (qp.py:158-181); each lane writes its own rows
+#pragma unroll
+    for (int s = 0; s < SN; ++s)
+        if (P.dp && inN[s]) P.dp[qp * N + r + 16 * s] = dxh[s];
+#pragma unroll
+    for (int s = 0; s < SM; ++s)
+        if (P.dh && inM[s]) P.dh[qp * M + r + 16 * s] = -dlam[s];
+    if (E > 0) {
+#pragma unroll
+        for (int s = 0; s < SE; ++s)
+            if (P.db && inE[s]) P.db[qp * E + r + 16 * s] = -dyt[s];
+    }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        const double zj = BC(zh, j), dxj = BC(dxh, j);
+        if (P.dQ) {
+#pragma unroll
+            for (int s = 0; s < SN; ++s)
+                if (inN[s]) P.dQ[(qp * N + r + 16 * s) * N + j] = 0.5 * (dxh[s] * zj + zh[s] * dxj);
+        }
+        if (P.dG) {
+#pragma unroll
+            for (int s = 0; s < SM; ++s)
+                if (inM[s]) P.dG[(qp * M + r + 16 * s) * N + j] = dlam[s] * zj + lam[s] * dxj;
+        }
+        if (P.dA && E > 0) {
+#pragma unroll
+            for (int s = 0; s < SE; ++s)
+                if (inE[s]) P.dA[(qp * E + r + 16 * s) * N + j] = dyt[s] * zj + nu[s] * dxj;
+        }
+    }
+    if (r == 0 && P.info) { P.info[2 * qp] = st.status; P.info[2 * qp + 1] = 0; }
+}
+
+template <class C, class K>
+int launch(K kernel, const KParams &P, void *stream)
+{
+    const size_t lds = (size_t)4 * C::ldsQPpad * sizeof(double);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DQP_ERR_LAUNCH;
+    const int blocks = (P.B + 3) / 4;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+}  // namespace r16
+
+#define DQP_R16_SIZES(X) X(30, 30, 15) X(10, 5, 3) X(12, 8, 0)
+
+int r16_forward(const KParams &P, void *stream)
+{
+#define X(n, m, e)                                                                     \
+    if (P.N == n && P.M == m && P.E == e)                                              \
+        return r16::launch<r16::Cfg<n, m, e>>(r16::forward_kernel<r16::Cfg<n, m, e>>, P, stream);
+    DQP_R16_SIZES(X)
+#undef X
+    return 1;
+}
+
+int r16_backward(const KParams &P, void *stream)
+{
+#define X(n, m, e)                                                                     \
+    if (P.N == n && P.M == m && P.E == e)                                              \
+        return r16::launch<r16::Cfg<n, m, e>>(r16::backward_kernel<r16::Cfg<n, m, e>>, P, stream);
+    DQP_R16_SIZES(X)
+#undef X
+    return 1;
+}
+
+}  // namespace dqp

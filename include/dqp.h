@@ -51,6 +51,8 @@ enum {
 #define DQP_FLAG_DENSE_BACKWARD 1u /* backward of DenseQPFunction (qp.py:239-270): d = lam/slack
                                       without the 1e-8 clamps of QPFunction (qp.py:149)   */
 
+#define DQP_FLAG_GENERIC_ONLY 2u   /* testing: skip the size-specialised DPP-row kernels     */
+
 typedef struct dqp_dims {
     int32_t nbatch;
     int32_t nz;
