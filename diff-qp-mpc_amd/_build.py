@@ -30,11 +30,23 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
-    cmd = [hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-fvisibility=hidden", "-o", SO] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    # The DPP-row kernels keep whole matrices in VGPR arrays: every loop over a register index
+    # must be fully unrolled, far beyond clang's default pragma-unroll budget.
+    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+             "-mllvm", "-pragma-unroll-threshold=10000000", "-mllvm", "-unroll-threshold=10000000"]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((subprocess.Popen(cmd), cmd))
+        objs.append(obj)
+    for pr, cmd in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] + objs)
     return SO
 
 

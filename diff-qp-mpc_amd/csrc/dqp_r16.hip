@@ -263,14 +263,17 @@ __device__ __forceinline__ void trsv_rows(const double (&L)[S][N], const double 
 // ------------------------------------------------------------------ packed-triangle LDS helpers
 // LDS holds, per QP, the packed lower triangle P[tri(i) + j], j <= i.
 template <int S, int N>
-__device__ __forceinline__ void tri_store(double *P, const double (&L)[S][N], int r)
+__device__ __forceinline__ void tri_store(double *P, const double (&L)[S][N], int r, double *dummy)
 {
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int i = r + 16 * s;
 #pragma unroll
-        for (int j = 0; j < N; ++j)
-            if (j <= 16 * s + 15 && i < N && j <= i) P[tri(i) + j] = L[s][j];
+        for (int j = 0; j < N; ++j) {
+            if (j > 16 * s + 15) continue;
+            double *dst = (i < N && j <= i) ? P + tri(i) + j : dummy;
+            *dst = L[s][j];
+        }
     }
 }
 
@@ -343,7 +346,8 @@ template <int N_, int M_, int E_> struct Cfg {
     static constexpr int EC = E_ > 0 ? E_ : 1;            // column count for E-sized arrays
     // packed triangles in LDS, per QP (doubles)
     static constexpr int oR = 0, oLq = tri(M_), oL1 = tri(M_) + tri(N_);
-    static constexpr int ldsQP = tri(M_) + tri(N_) + tri(E_) + 1;
+    static constexpr int oDummy = tri(M_) + tri(N_) + tri(E_);   // 16 write-only sink slots
+    static constexpr int ldsQP = tri(M_) + tri(N_) + tri(E_) + 16;
     static constexpr int ldsQPpad = (ldsQP + 1) & ~1;
 };
 
@@ -356,52 +360,52 @@ template <class C> struct State {
     int status;
 };
 
+// Row-distributed load of an nrows x NC matrix (rows beyond nrows are zero).
+template <int S, int NC>
+__device__ __forceinline__ void load_rows(const double *src, int nrows, double (&dst)[S][NC], int r)
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = r + 16 * s;
+        const double *row = src + (i < nrows ? i : nrows - 1) * NC;
+        const double keep = i < nrows ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) dst[s][j] = row[j];
+        if (16 * s + 15 >= nrows) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) dst[s][j] *= keep;
+        }
+    }
+}
+
 // One-time factorisations (reference: pre_factor_kkt, batch.py:377-428), all in registers.
-// Writes packed R, Lq, L1 to this QP's LDS block.
+// Writes packed R, Lq, L1 to this QP's LDS block.  Phases are separated by scheduling
+// barriers so that the live register set of one phase is not extended into the next.
 template <class C>
 __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, double *lds, State<C> &st)
 {
     constexpr int N = C::N, M = C::M, E = C::E, SN = C::SN, SM = C::SM, SE = C::SE;
+    double *dummy = lds + C::oDummy + r;
     st.status = DQP_STATUS_OK;
-    {
+    {   // phase A: Q -> Lq (Cholesky) -> packed LDS
         double Lq[SN][N];
-        const double *Q = P.Q + qp * P.sQ;
-#pragma unroll
-        for (int s = 0; s < SN; ++s) {
-            const int i = r + 16 * s;
-            const double *row = Q + (i < N ? i : 0) * N;
-#pragma unroll
-            for (int j = 0; j < N; ++j) Lq[s][j] = (i < N) ? row[j] : (i == j ? 1.0 : 0.0);
-        }
-        // pad rows (i >= N) do not exist for j < N, so the "identity" padding never triggers;
-        // pad rows simply stay zero and are masked wherever a pivot would be read.
+        load_rows<SN, N>(P.Q + qp * P.sQ, N, Lq, r);
         if (!chol_rows<SN, N>(Lq, st.rdq, r)) st.status = DQP_STATUS_Q_NOT_PD;
+        tri_store<SN, N>(lds + C::oLq, Lq, r, dummy);
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
 
-        // rows of G and A:  row <- row Lq^-T   (row[j] = (row[j] - sum_{k<j} row[k] Lq[j][k]) / Lq[j][j])
-        const double *G = P.G + qp * P.sG;
-#pragma unroll
-        for (int s = 0; s < SM; ++s) {
-            const int i = r + 16 * s;
-            const double *row = G + (i < M ? i : 0) * N;
-#pragma unroll
-            for (int j = 0; j < N; ++j) st.Gh[s][j] = (i < M) ? row[j] : 0.0;
-        }
-        if (E > 0) {
-            const double *A = P.A + qp * P.sA;
-#pragma unroll
-            for (int s = 0; s < SE; ++s) {
-                const int i = r + 16 * s;
-                const double *row = A + (i < E ? i : 0) * N;
-#pragma unroll
-                for (int j = 0; j < N; ++j) st.Ah[s][j] = (i < E) ? row[j] : 0.0;
-            }
-        }
+    // phase B: rows of G and A:  row <- row Lq^-T, with Lq[j][k] read (row-uniformly) from LDS
+    load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
+    if (E > 0) load_rows<SE, N>(P.A + qp * P.sA, E, st.Ah, r);
+    {
+        const double *Lp = lds + C::oLq;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            const int sj = j >> 4, lj = j & 15;
 #pragma unroll
             for (int k = 0; k < j; ++k) {
-                const double ljk = rb(Lq[sj][k], lj);
+                const double ljk = Lp[tri(j) + k];
 #pragma unroll
                 for (int s = 0; s < SM; ++s) st.Gh[s][j] = fma(-st.Gh[s][k], ljk, st.Gh[s][j]);
                 if (E > 0) {
@@ -409,7 +413,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
                     for (int s = 0; s < SE; ++s) st.Ah[s][j] = fma(-st.Ah[s][k], ljk, st.Ah[s][j]);
                 }
             }
-            const double rj = rb(st.rdq[sj], lj);
+            const double rj = BC(st.rdq, j);
 #pragma unroll
             for (int s = 0; s < SM; ++s) st.Gh[s][j] *= rj;
             if (E > 0) {
@@ -417,84 +421,75 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
                 for (int s = 0; s < SE; ++s) st.Ah[s][j] *= rj;
             }
         }
-        tri_store<SN, N>(lds + C::oLq, Lq, r);
     }
+    __builtin_amdgcn_sched_barrier(0);
 
+    double W[SM][C::EC];
     if (E > 0) {
         constexpr int EC = C::EC;
-        double L1[SE][EC];
-        // S11 = Ah Ah^T
+        {   // phase C: S11 = Ah Ah^T = L1 L1^T ; At = L1^-1 Ah
+            double L1[SE][EC];
 #pragma unroll
-        for (int j = 0; j < EC; ++j) {
-            const int sj = j >> 4, lj = j & 15;
+            for (int j = 0; j < EC; ++j) {
+                const int sj = j >> 4, lj = j & 15;
 #pragma unroll
-            for (int s = 0; s < SE; ++s) L1[s][j] = 0.0;
+                for (int s = 0; s < SE; ++s) L1[s][j] = 0.0;
+#pragma unroll
+                for (int c = 0; c < N; ++c) {
+                    const double ab = rb(st.Ah[sj][c], lj);
+#pragma unroll
+                    for (int s = 0; s < SE; ++s) L1[s][j] = fma(st.Ah[s][c], ab, L1[s][j]);
+                }
+            }
+            if (!chol_rows<SE, EC>(L1, st.rd1, r) && st.status == DQP_STATUS_OK)
+                st.status = DQP_STATUS_A_RANK_DEF;
+            // eliminate with unscaled rows, scale once at the end
+#pragma unroll
+            for (int g = 0; g < EC; ++g) {
+                const int sg = g >> 4, lg = g & 15;
+                const double rg = rb(st.rd1[sg], lg);
+                double m[SE];
+#pragma unroll
+                for (int s = 0; s < SE; ++s) {
+                    if (16 * s + 15 <= g) m[s] = 0.0;
+                    else if (16 * s > g) m[s] = L1[s][g] * rg;
+                    else m[s] = (r > lg) ? L1[s][g] * rg : 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < N; ++c) {
+                    const double ub = rb(st.Ah[sg][c], lg);
+#pragma unroll
+                    for (int s = 0; s < SE; ++s)
+                        if (16 * s + 15 > g) st.Ah[s][c] = fma(-m[s], ub, st.Ah[s][c]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < SE; ++s)
+#pragma unroll
+                for (int c = 0; c < N; ++c) st.Ah[s][c] *= st.rd1[s];
+            tri_store<SE, EC>(lds + C::oL1, L1, r, dummy);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // W = Gh At^T  (M x E)
+#pragma unroll
+        for (int e = 0; e < EC; ++e) {
+            const int se = e >> 4, le = e & 15;
+#pragma unroll
+            for (int s = 0; s < SM; ++s) W[s][e] = 0.0;
 #pragma unroll
             for (int c = 0; c < N; ++c) {
-                const double ab = rb(st.Ah[sj][c], lj);
+                const double ab = rb(st.Ah[se][c], le);
 #pragma unroll
-                for (int s = 0; s < SE; ++s) L1[s][j] = fma(st.Ah[s][c], ab, L1[s][j]);
+                for (int s = 0; s < SM; ++s) W[s][e] = fma(st.Gh[s][c], ab, W[s][e]);
             }
         }
-        if (!chol_rows<SE, EC>(L1, st.rd1, r) && st.status == DQP_STATUS_OK)
-            st.status = DQP_STATUS_A_RANK_DEF;
-        // At = L1^-1 Ah: eliminate with unscaled rows, scale once at the end
-#pragma unroll
-        for (int g = 0; g < EC; ++g) {
-            const int sg = g >> 4, lg = g & 15;
-            const double rg = rb(st.rd1[sg], lg);
-            double m[SE];
-#pragma unroll
-            for (int s = 0; s < SE; ++s) {
-                if (16 * s + 15 <= g) m[s] = 0.0;
-                else if (16 * s > g) m[s] = L1[s][g] * rg;
-                else m[s] = (r > lg) ? L1[s][g] * rg : 0.0;
-            }
-#pragma unroll
-            for (int c = 0; c < N; ++c) {
-                const double ub = rb(st.Ah[sg][c], lg);
-#pragma unroll
-                for (int s = 0; s < SE; ++s)
-                    if (16 * s + 15 > g) st.Ah[s][c] = fma(-m[s], ub, st.Ah[s][c]);
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < SE; ++s)
-#pragma unroll
-            for (int c = 0; c < N; ++c) st.Ah[s][c] *= st.rd1[s];
-        tri_store<SE, EC>(lds + C::oL1, L1, r);
     } else {
 #pragma unroll
         for (int s = 0; s < SE; ++s) st.rd1[s] = 0.0;
     }
+    __builtin_amdgcn_sched_barrier(0);
 
-    {   // Gbar = Gh - (Gh At^T) At ;  R = Gbar Gbar^T (packed lower triangle -> LDS)
-        double Gb[SM][N];
-#pragma unroll
-        for (int s = 0; s < SM; ++s)
-#pragma unroll
-            for (int c = 0; c < N; ++c) Gb[s][c] = st.Gh[s][c];
-        if (E > 0) {
-#pragma unroll
-            for (int e = 0; e < C::EC; ++e) {
-                const int se = e >> 4, le = e & 15;
-                double w[SM];
-#pragma unroll
-                for (int s = 0; s < SM; ++s) w[s] = 0.0;
-#pragma unroll
-                for (int c = 0; c < N; ++c) {
-                    const double ab = rb(st.Ah[se][c], le);
-#pragma unroll
-                    for (int s = 0; s < SM; ++s) w[s] = fma(st.Gh[s][c], ab, w[s]);
-                }
-#pragma unroll
-                for (int c = 0; c < N; ++c) {
-                    const double ab = rb(st.Ah[se][c], le);
-#pragma unroll
-                    for (int s = 0; s < SM; ++s) Gb[s][c] = fma(-w[s], ab, Gb[s][c]);
-                }
-            }
-        }
+    {   // phase D: R = Gh Gh^T - W W^T (the reference's own form, batch.py:399,420), packed -> LDS
         double *Rp = lds + C::oR;
 #pragma unroll
         for (int j = 0; j < M; ++j) {
@@ -504,19 +499,31 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
             for (int s = 0; s < SM; ++s) acc[s] = 0.0;
 #pragma unroll
             for (int c = 0; c < N; ++c) {
-                const double gb = rb(Gb[sj][c], lj);
+                const double gb = rb(st.Gh[sj][c], lj);
 #pragma unroll
                 for (int s = 0; s < SM; ++s)
-                    if (16 * s + 15 >= j) acc[s] = fma(Gb[s][c], gb, acc[s]);
+                    if (16 * s + 15 >= j) acc[s] = fma(st.Gh[s][c], gb, acc[s]);
+            }
+            if (E > 0) {
+#pragma unroll
+                for (int e = 0; e < C::EC; ++e) {
+                    const double wb = rb(W[sj][e], lj);
+#pragma unroll
+                    for (int s = 0; s < SM; ++s)
+                        if (16 * s + 15 >= j) acc[s] = fma(-W[s][e], wb, acc[s]);
+                }
             }
 #pragma unroll
             for (int s = 0; s < SM; ++s) {
+                if (16 * s + 15 < j) continue;
                 const int i = r + 16 * s;
-                if (16 * s + 15 >= j && i < M && j <= i) Rp[tri(i) + j] = acc[s];
+                double *dst = (i < M && j <= i) ? Rp + tri(i) + j : dummy;
+                *dst = acc[s];
             }
         }
     }
     __syncthreads();   // factor_T reads R[j][i] written by the lane that owns row j
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // T = R + diag(dinv) (full square, row-distributed) from the packed triangle in LDS, then LU.
