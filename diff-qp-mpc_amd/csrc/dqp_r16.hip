@@ -101,36 +101,30 @@ __device__ __forceinline__ void mv_nat(const double (&Mx)[SR][NC], const double 
     }
 }
 
-// Reduce-scatter over the 16 lanes of a DPP row: on entry every lane holds its partial p[c] of
-// NC column sums; on exit y[c >> 4] on lane (c & 15) holds the total of column c.  Four mirror
+// Reduce-scatter over the 16 lanes of a DPP row: on entry every lane holds its partials v[k]
+// of 16 column sums; the return value on lane k is the total of column k.  Four mirror
 // butterflies (row_mirror, row_half_mirror, quad reverse, quad swap) halve the live values.
-template <int NC, int SY>
-__device__ __forceinline__ void reduce_scatter(double (&p)[NC], double (&y)[SY], int r)
+__device__ __forceinline__ double reduce_scatter16(const double (&v)[16], int r)
 {
     const bool h8 = (r & 8) != 0, h4 = (r & 4) != 0, h2 = (r & 2) != 0, h1 = (r & 1) != 0;
+    double a[8], b4[4], c2[2];
 #pragma unroll
-    for (int g = 0; g < SY; ++g) {
-        double a[8], b4[4], c2[2];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const double lo = (16 * g + k < NC) ? p[16 * g + k] : 0.0;
-            const double hi = (16 * g + k + 8 < NC) ? p[(16 * g + k + 8 < NC) ? 16 * g + k + 8 : 0] : 0.0;
-            const double keep = h8 ? hi : lo, send = h8 ? lo : hi;
-            a[k] = keep + dppd<0x140>(send);                 // row_mirror: l <-> 15-l
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const double keep = h4 ? a[k + 4] : a[k], send = h4 ? a[k] : a[k + 4];
-            b4[k] = keep + dppd<0x141>(send);                // row_half_mirror: l <-> 7-l
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const double keep = h2 ? b4[k + 2] : b4[k], send = h2 ? b4[k] : b4[k + 2];
-            c2[k] = keep + dppd<0x1b>(send);                 // quad_perm [3,2,1,0]
-        }
-        const double keep = h1 ? c2[1] : c2[0], send = h1 ? c2[0] : c2[1];
-        y[g] = keep + dppd<0xb1>(send);                      // quad_perm [1,0,3,2]
+    for (int k = 0; k < 8; ++k) {
+        const double keep = h8 ? v[k + 8] : v[k], send = h8 ? v[k] : v[k + 8];
+        a[k] = keep + dppd<0x140>(send);                 // row_mirror: l <-> 15-l
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const double keep = h4 ? a[k + 4] : a[k], send = h4 ? a[k] : a[k + 4];
+        b4[k] = keep + dppd<0x141>(send);                // row_half_mirror: l <-> 7-l
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const double keep = h2 ? b4[k + 2] : b4[k], send = h2 ? b4[k] : b4[k + 2];
+        c2[k] = keep + dppd<0x1b>(send);                 // quad_perm [3,2,1,0]
+    }
+    const double keep = h1 ? c2[1] : c2[0], send = h1 ? c2[0] : c2[1];
+    return keep + dppd<0xb1>(send);                      // quad_perm [1,0,3,2]
 }
 
 // y = M^T v   (M row-distributed SR x NC, v distributed over the rows; y distributed length NC)
@@ -138,15 +132,23 @@ template <int SR, int NC, int SY>
 __device__ __forceinline__ void mv_tr(const double (&Mx)[SR][NC], const double (&v)[SR],
                                       double (&y)[SY], int r)
 {
-    double p[NC];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        double a = Mx[0][c] * v[0];
+    for (int g = 0; g < SY; ++g) {
+        double p[16];
 #pragma unroll
-        for (int s = 1; s < SR; ++s) a = fma(Mx[s][c], v[s], a);
-        p[c] = a;
+        for (int k = 0; k < 16; ++k) {
+            const int c = 16 * g + k;
+            if (c < NC) {
+                double a = Mx[0][c < NC ? c : 0] * v[0];
+#pragma unroll
+                for (int s = 1; s < SR; ++s) a = fma(Mx[s][c < NC ? c : 0], v[s], a);
+                p[k] = a;
+            } else {
+                p[k] = 0.0;
+            }
+        }
+        y[g] = reduce_scatter16(p, r);
     }
-    reduce_scatter<NC, SY>(p, y, r);
 }
 
 // ------------------------------------------------------------------ factorizations in registers
@@ -339,6 +341,28 @@ __device__ __forceinline__ void tri_solve_T(const double *P, const double (&rd)[
     }
 }
 
+// distributed vector <-> LDS (each lane touches only its own elements: no barrier needed)
+template <int S>
+__device__ __forceinline__ void vec_put(double *P, const double (&v)[S], int n, int r, double *dummy)
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = r + 16 * s;
+        double *dst = i < n ? P + i : dummy;
+        *dst = v[s];
+    }
+}
+template <int S>
+__device__ __forceinline__ void vec_get(const double *P, double (&v)[S], int n, int r)
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = r + 16 * s;
+        const double x = P[i < n ? i : n - 1];
+        v[s] = i < n ? x : 0.0;
+    }
+}
+
 // ------------------------------------------------------------------ per-size configuration
 template <int N_, int M_, int E_> struct Cfg {
     static constexpr int N = N_, M = M_, E = E_;
@@ -346,8 +370,12 @@ template <int N_, int M_, int E_> struct Cfg {
     static constexpr int EC = E_ > 0 ? E_ : 1;            // column count for E-sized arrays
     // packed triangles in LDS, per QP (doubles)
     static constexpr int oR = 0, oLq = tri(M_), oL1 = tri(M_) + tri(N_);
-    static constexpr int oDummy = tri(M_) + tri(N_) + tri(E_);   // 16 write-only sink slots
-    static constexpr int ldsQP = tri(M_) + tri(N_) + tri(E_) + 16;
+    // distributed vectors parked in LDS (element i at offset + i): p^, h, b~, best iterate
+    static constexpr int oPh = tri(M_) + tri(N_) + tri(E_);
+    static constexpr int oH = oPh + N_, oBt = oH + M_;
+    static constexpr int oBx = oBt + E_, oBs = oBx + N_, oBz = oBs + M_, oBy = oBz + M_;
+    static constexpr int oDummy = oBy + E_;                      // 16 write-only sink slots
+    static constexpr int ldsQP = oDummy + 16;
     static constexpr int ldsQPpad = (ldsQP + 1) & ~1;
 };
 
@@ -636,6 +664,10 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     for (int s = 0; s < SE; ++s) bt[s] = (E > 0 && inE[s]) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
     tri_solve<SN, N>(lds + C::oLq, st.rdq, ph, r);
     if (E > 0) tri_solve<SE, C::EC>(lds + C::oL1, st.rd1, bt, r);
+    double *dummy = lds + C::oDummy + r;
+    vec_put<SN>(lds + C::oPh, ph, N, r, dummy);
+    vec_put<SM>(lds + C::oH, hh, M, r, dummy);
+    if (E > 0) vec_put<SE>(lds + C::oBt, bt, E, r, dummy);
 
     double T[SM][M], rdu[SM];
     double xh[SN], s_[SM], z[SM], yt[SE];
@@ -664,13 +696,11 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         }
     }
 
-    double bxh[SN], bs[SM], bz[SM], byt[SE], best = INFINITY;
-#pragma unroll
-    for (int s = 0; s < SN; ++s) bxh[s] = xh[s];
-#pragma unroll
-    for (int s = 0; s < SM; ++s) { bs[s] = s_[s]; bz[s] = z[s]; }
-#pragma unroll
-    for (int s = 0; s < SE; ++s) byt[s] = yt[s];
+    double best = INFINITY;
+    vec_put<SN>(lds + C::oBx, xh, N, r, dummy);
+    vec_put<SM>(lds + C::oBs, s_, M, r, dummy);
+    vec_put<SM>(lds + C::oBz, z, M, r, dummy);
+    if (E > 0) vec_put<SE>(lds + C::oBy, yt, E, r, dummy);
     bool have_best = false, done = false;
     int nNot = 0, iters = 0;
 
@@ -678,8 +708,9 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         // residuals in hat coordinates                                    batch.py:93-108
         double rxh[SN], ryt[SE], rz[SM], tmpN[SN];
         mv_tr<SM, N, SN>(st.Gh, z, rxh, r);
+        vec_get<SN>(lds + C::oPh, tmpN, N, r);
 #pragma unroll
-        for (int s = 0; s < SN; ++s) rxh[s] += xh[s] + ph[s];
+        for (int s = 0; s < SN; ++s) rxh[s] += xh[s] + tmpN[s];
 #pragma unroll
         for (int s = 0; s < SE; ++s) ryt[s] = 0.0;
         if (E > 0) {
@@ -687,14 +718,18 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
 #pragma unroll
             for (int s = 0; s < SN; ++s) rxh[s] += tmpN[s];
             mv_nat<SE, N, SN>(st.Ah, xh, ryt, false);
+            double btl[SE];
+            vec_get<SE>(lds + C::oBt, btl, E, r);
 #pragma unroll
-            for (int s = 0; s < SE; ++s) ryt[s] -= bt[s];
+            for (int s = 0; s < SE; ++s) ryt[s] -= btl[s];
         }
         mv_nat<SM, N, SN>(st.Gh, xh, rz, false);
         double sz = 0.0, nz2 = 0.0, nx2 = 0.0, ny2 = 0.0;
+        double hl[SM];
+        vec_get<SM>(lds + C::oH, hl, M, r);
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
-            rz[s] = inM[s] ? rz[s] + s_[s] - hh[s] : 0.0;
+            rz[s] = inM[s] ? rz[s] + s_[s] - hl[s] : 0.0;
             sz = fma(s_[s], z[s], sz);
             nz2 = fma(rz[s], rz[s], nz2);
         }
@@ -718,12 +753,10 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             iters = it + 1;
             if (!have_best || resid < best) {
                 nNot = 0; have_best = true; best = resid;
-#pragma unroll
-                for (int s = 0; s < SN; ++s) bxh[s] = xh[s];
-#pragma unroll
-                for (int s = 0; s < SM; ++s) { bs[s] = s_[s]; bz[s] = z[s]; }
-#pragma unroll
-                for (int s = 0; s < SE; ++s) byt[s] = yt[s];
+                vec_put<SN>(lds + C::oBx, xh, N, r, dummy);
+                vec_put<SM>(lds + C::oBs, s_, M, r, dummy);
+                vec_put<SM>(lds + C::oBz, z, M, r, dummy);
+                if (E > 0) vec_put<SE>(lds + C::oBy, yt, E, r, dummy);
             } else {
                 nNot += 1;
             }
@@ -785,6 +818,13 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     }
 
     // back to the caller's coordinates: x = Lq^-T xh, y = L1^-T yt
+    double bxh[SN], bs[SM], bz[SM], byt[SE];
+    vec_get<SN>(lds + C::oBx, bxh, N, r);
+    vec_get<SM>(lds + C::oBs, bs, M, r);
+    vec_get<SM>(lds + C::oBz, bz, M, r);
+#pragma unroll
+    for (int s = 0; s < SE; ++s) byt[s] = 0.0;
+    if (E > 0) vec_get<SE>(lds + C::oBy, byt, E, r);
     tri_solve_T<SN, N>(lds + C::oLq, st.rdq, bxh, r);
     if (E > 0) tri_solve_T<SE, C::EC>(lds + C::oL1, st.rd1, byt, r);
     if (live) {
