@@ -19,6 +19,7 @@ struct KParams {
     const double *zin, *lamin, *nuin, *slackin, *gin;
     double *dQ, *dp, *dG, *dh, *dA, *db;
     int32_t *info;
+    unsigned long long *stamps;   // diagnostic: s_memtime at phase boundaries (16 per workgroup) or NULL
     int B, N, M, E;
     int ldz, ldm, lde, ldt;
     double eps, stallTol;
@@ -30,6 +31,7 @@ struct KParams {
 // DPP-row kernels (dqp_r16.hip): 4 QPs per wavefront for compile-time sizes <= 32.
 // Return DQP_OK / error, or 1 when no instantiation matches (caller falls back to the
 // generic kernels of dqp_pdipm.hip).
+extern unsigned long long *g_debug_stamps;
 int r16_forward(const KParams &P, void *stream);
 int r16_backward(const KParams &P, void *stream);
 

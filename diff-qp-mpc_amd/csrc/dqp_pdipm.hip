@@ -608,6 +608,7 @@ __global__ __launch_bounds__(WAVE) void qp_backward_kernel(KParams P)
 
 int fill_params(const dqp_dims *d, const dqp_opts *o, KParams &P, size_t &lds_bytes)
 {
+    P.stamps = dqp::g_debug_stamps;
     if (!d) return DQP_ERR_BAD_ARG;
     if (d->nbatch < 0 || d->nz <= 0 || d->nineq <= 0 || d->neq < 0) return DQP_ERR_BAD_ARG;
     if (d->nz > DQP_MAX_DIM || d->nineq > DQP_MAX_DIM || d->neq > DQP_MAX_DIM) return DQP_ERR_TOO_LARGE;
@@ -645,7 +646,16 @@ int launch(K kernel, const KParams &P, size_t lds_bytes, void *stream)
 
 }  // namespace
 
+namespace dqp { unsigned long long *g_debug_stamps = nullptr; }
+
 extern "C" {
+
+// Diagnostic hook (not part of include/dqp.h): device buffer of 16 x uint64 per workgroup that
+// the DPP-row kernels fill with s_memtime stamps at phase boundaries; NULL disables.
+__attribute__((visibility("default"))) void dqp_debug_set_stamps(void *dev_ptr)
+{
+    dqp::g_debug_stamps = (unsigned long long *)dev_ptr;
+}
 
 __attribute__((visibility("default"))) int dqp_version(void) { return DQP_VERSION; }
 

@@ -80,6 +80,23 @@ __device__ __forceinline__ double frsqrt(double d)
     return y;
 }
 
+// Diagnostic phase stamps: compiled in only with -DDQP_STAMPS (tools/stamps.py builds that
+// variant itself).  Even a never-taken stamp branch perturbs register allocation of the
+// fully unrolled kernels by 2-3x, so the shipped build contains none.
+#ifndef DQP_STAMPS
+#define STAMP(P, i) do { } while (0)
+#else
+#define STAMP(P, i)                                                                  \
+    do {                                                                             \
+        if ((P).stamps) {                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                       \
+            const unsigned long long t__ = __builtin_readcyclecounter();             \
+            if (threadIdx.x == 0) (P).stamps[blockIdx.x * 16 + (i)] = t__;           \
+            __builtin_amdgcn_sched_barrier(0);                                       \
+        }                                                                            \
+    } while (0)
+#endif
+
 constexpr __host__ __device__ int slots(int n) { return (n + 15) / 16; }
 constexpr __host__ __device__ int tri(int i) { return i * (i + 1) / 2; }
 
@@ -415,6 +432,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     constexpr int N = C::N, M = C::M, E = C::E, SN = C::SN, SM = C::SM, SE = C::SE;
     double *dummy = lds + C::oDummy + r;
     st.status = DQP_STATUS_OK;
+    STAMP(P, 0);
     {   // phase A: Q -> Lq (Cholesky) -> packed LDS
         double Lq[SN][N];
         load_rows<SN, N>(P.Q + qp * P.sQ, N, Lq, r);
@@ -423,6 +441,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(P, 1);
 
     // phase B: rows of G and A:  row <- row Lq^-T, with Lq[j][k] read (row-uniformly) from LDS
     load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
@@ -451,6 +470,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(P, 2);
 
     double W[SM][C::EC];
     if (E > 0) {
@@ -498,6 +518,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
             tri_store<SE, EC>(lds + C::oL1, L1, r, dummy);
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(P, 3);
         // W = Gh At^T  (M x E)
 #pragma unroll
         for (int e = 0; e < EC; ++e) {
@@ -516,6 +537,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         for (int s = 0; s < SE; ++s) st.rd1[s] = 0.0;
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(P, 4);
 
     {   // phase D: R = Gh Gh^T - W W^T (the reference's own form, batch.py:399,420), packed -> LDS
         double *Rp = lds + C::oR;
@@ -552,6 +574,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     }
     __syncthreads();   // factor_T reads R[j][i] written by the lane that owns row j
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(P, 5);
 }
 
 // T = R + diag(dinv) (full square, row-distributed) from the packed triangle in LDS, then LU.
@@ -696,6 +719,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         }
     }
 
+    STAMP(P, 6);
     double best = INFINITY;
     vec_put<SN>(lds + C::oBx, xh, N, r, dummy);
     vec_put<SM>(lds + C::oBs, s_, M, r, dummy);
@@ -766,11 +790,13 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         }
         // the wave leaves when all four of its QPs are done
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+        if (it == 1) STAMP(P, 9);
 
         double dinv[SM];
 #pragma unroll
         for (int s = 0; s < SM; ++s) dinv[s] = inM[s] ? s_[s] / z[s] : 0.0;   // 1/d, d = z/s
         factor_T<C>(lds, T, dinv, rdu, r);
+        if (it == 1) STAMP(P, 10);
 
         // affine direction (rs = z => rs/d = s)                             batch.py:151
         double dza[SM], dsa[SM];
@@ -782,6 +808,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             am = fmin(am, fmin(ratio(z[s], dza[s], inM[s]), ratio(s_[s], dsa[s], inM[s])));
         }
         double alpha = fmin(row_min(am), 1.0);
+        if (it == 1) STAMP(P, 11);
         double t3 = 0.0;
 #pragma unroll
         for (int s = 0; s < SM; ++s)
@@ -797,6 +824,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             dzc[s] = -rsc[s] * dinv[s];
         }
         lu_solve<SM, M>(T, rdu, dzc, r);
+        if (it == 1) STAMP(P, 12);
         am = INFINITY;
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
@@ -807,6 +835,8 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         double dxh[SN], dyt[SE];
         kkt_xy<C>(st, rxh, ryt, dz, dxh, dyt, r);
         alpha = fmin(0.999 * row_min(am), 1.0);
+        if (it == 1) STAMP(P, 13);
+        if (it == 0) STAMP(P, 8);
         if (!done) {
 #pragma unroll
             for (int s = 0; s < SN; ++s) xh[s] = fma(alpha, dxh[s], xh[s]);
@@ -818,6 +848,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     }
 
     // back to the caller's coordinates: x = Lq^-T xh, y = L1^-T yt
+    STAMP(P, 7);
     double bxh[SN], bs[SM], bz[SM], byt[SE];
     vec_get<SN>(lds + C::oBx, bxh, N, r);
     vec_get<SM>(lds + C::oBs, bs, M, r);
@@ -844,6 +875,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             if (P.best_resid) P.best_resid[qp] = best;
         }
     }
+    STAMP(P, 14);
 }
 
 template <class C>

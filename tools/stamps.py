@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle split of the DPP-row forward kernel (s_memtime stamps)."""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import subprocess
+import bench
+from diff_qp_mpc_amd import _lib, _build
+
+# build the instrumented variant next to the product library (never loaded by the product)
+so = os.path.join(_build.CSRC, "libdqp_hip_stamps.so")
+if not os.path.exists(so):
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+                           "-DDQP_STAMPS", "-mllvm", "-pragma-unroll-threshold=10000000", "-mllvm",
+                           "-unroll-threshold=10000000", "-o", so] +
+                          [os.path.join(_build.CSRC, f) for f in _build.SOURCES])
+_build.SO = so
+lib = _lib.load()
+lib.dqp_debug_set_stamps.argtypes = [ctypes.c_void_p]
+dev = torch.device("cuda", 0)
+hp = bench.HotPath(dev, bench.family_R(0, 4096, 30, 30, 15))
+hp.forward(); hp.backward(); torch.cuda.synchronize()
+nb = 1024
+st = torch.zeros(nb, 16, dtype=torch.int64, device=dev)
+lib.dqp_debug_set_stamps(ctypes.c_void_p(st.data_ptr()))
+hp.forward(); torch.cuda.synchronize()
+s = st.cpu().numpy().astype(np.float64)
+lib.dqp_debug_set_stamps(ctypes.c_void_p(0))
+names = {1: "A load Q+chol+store", 2: "B G,A rows * Lq^-T", 3: "C S11,chol,At", 4: "W", 5: "D R",
+         6: "p^,b~, init factor+solve"}
+prev = s[:, 0]
+for k in range(1, 7):
+    d = s[:, k] - prev
+    print("%-28s median %8.0f  min %8.0f max %8.0f  (s_memtime ticks)" % (names[k], np.median(d), d.min(), d.max()))
+    prev = s[:, k]
+print("iteration 0 total            median %8.0f" % np.median(s[:, 8] - s[:, 6]))
+it = [("residuals+resid", 9, None), ("factor_T", 10, 9), ("affine solve", 11, 10), ("corrector solve", 12, 11), ("xy + step", 13, 12)]
+for name, k, p in it[1:]:
+    print("iter1 %-22s median %8.0f" % (name, np.median(s[:, k] - s[:, p])))
+print("loop total (all iterations)  median %8.0f  max %8.0f" % (np.median(s[:, 7] - s[:, 6]), (s[:, 7] - s[:, 6]).max()))
+print("epilogue                     median %8.0f" % np.median(s[:, 14] - s[:, 7]))
+print("kernel total                 median %8.0f  max %8.0f" % (np.median(s[:, 14] - s[:, 0]), (s[:, 14] - s[:, 0]).max()))
+print("iters: mean %.2f max %d" % (hp.info[:, 1].float().mean().item(), hp.info[:, 1].max().item()))
