@@ -34,7 +34,12 @@ DQP_MAX_DIM = 64
 
 # every symbol include/dqp.h declares
 SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes",
-           "dqp_qp_forward", "dqp_qp_backward")
+           "dqp_qp_forward", "dqp_qp_backward", "dqp_mpc_assemble", "dqp_mpc_assemble_backward")
+
+
+class dqp_mpc_dims(ctypes.Structure):
+    _fields_ = [("nbatch", ctypes.c_int32), ("n_state", ctypes.c_int32), ("n_ctrl", ctypes.c_int32),
+                ("T", ctypes.c_int32), ("has_bounds", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 _lib = None
 
@@ -66,6 +71,10 @@ def load():
     lib.dqp_qp_forward.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 14
     lib.dqp_qp_backward.restype = ctypes.c_int
     lib.dqp_qp_backward.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 17
+    lib.dqp_mpc_assemble.restype = ctypes.c_int
+    lib.dqp_mpc_assemble.argtypes = [ctypes.POINTER(dqp_mpc_dims)] + [_dp] * 14
+    lib.dqp_mpc_assemble_backward.restype = ctypes.c_int
+    lib.dqp_mpc_assemble_backward.argtypes = [ctypes.POINTER(dqp_mpc_dims)] + [_dp] * 10
     _lib = lib
     return lib
 

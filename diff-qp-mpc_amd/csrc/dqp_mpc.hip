@@ -1,0 +1,204 @@
+// dqp_mpc.hip -- MPC-structured QP assembly on the device.
+//
+// Replaces qpth/qp_wrapper.py:638-679 (compute_Qq_dense / compute_Ab_dense / compute_Gh_dense),
+// which build (Q,p,G,h,A,b) from the time-major MPC data with advanced-index scatters into
+// freshly zeroed tensors (three fills + five scatters per call).  Here one launch writes every
+// element of the six outputs exactly once (coalesced along the contiguous nz axis), and the
+// backward launch gathers the gradients of (C,c,F,f,x0) from (dQ,dp,dA,db).
+//
+// Layouts (fp64, contiguous):  C (T,B,nt,nt)  c (T,B,nt)  F (T-1,B,n,nt)  f (T-1,B,n)  x0 (B,n)
+//   z = per-timestep [x_t, u_t], nt = n+m, nz = T nt, neq = T n, nineq = 2 T m (or m without bounds)
+//   A rows: (T-1) n dynamics rows  F_t [x_t;u_t] - x_{t+1} = -f_t, then n rows  x_0 = x0.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dqp.h"
+
+namespace {
+
+struct MpcP {
+    const double *C, *c, *F, *f, *x0, *ul, *uu;
+    double *Q, *p, *G, *h, *A, *b;
+    const double *dQ, *dp, *dA, *db;
+    double *dC, *dc, *dF, *df, *dx0;
+    int B, n, m, T, bounds;
+};
+
+__global__ __launch_bounds__(256) void assemble_kernel(MpcP P)
+{
+    const int n = P.n, m = P.m, T = P.T, nt = n + m, nz = T * nt, neq = T * n;
+    const int nineq = P.bounds ? 2 * T * m : m;
+    const long long B = P.B;
+    const long long nQ = B * nz * nz, nA = B * neq * nz, nG = B * nineq * nz;
+    const long long np = B * nz, nb = B * neq, nh = B * nineq;
+    const long long total = nQ + nA + nG + np + nb + nh;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long e = idx;
+        if (e < nQ) {                                   // Q = blockdiag_t C[t,b]
+            const int col = e % nz; const long long rb = e / nz;
+            const int row = rb % nz; const long long b = rb / nz;
+            const int t = row / nt, i = row - t * nt, tc = col / nt, j = col - tc * nt;
+            P.Q[e] = (t == tc) ? P.C[(((long long)t * B + b) * nt + i) * nt + j] : 0.0;
+            continue;
+        }
+        e -= nQ;
+        if (e < nA) {
+            const int col = e % nz; const long long rb = e / nz;
+            const int row = rb % neq; const long long b = rb / neq;
+            const int t = row / n, i = row - t * n, tc = col / nt, j = col - tc * nt;
+            double v = 0.0;
+            if (t < T - 1) {
+                if (tc == t) v = P.F[(((long long)t * B + b) * n + i) * nt + j];
+                else if (tc == t + 1 && j == i) v = -1.0;
+            } else if (tc == 0 && j == i) v = 1.0;
+            P.A[e] = v;
+            continue;
+        }
+        e -= nA;
+        if (e < nG) {
+            const int col = e % nz; const long long rb = e / nz;
+            const int row = rb % nineq;
+            const int tc = col / nt, j = col - tc * nt;
+            double v = 0.0;
+            if (P.bounds) {
+                const int k = row < T * m ? row : row - T * m;      // k = t m + ju
+                const int t = k / m, ju = k - t * m;
+                if (tc == t && j == n + ju) v = row < T * m ? 1.0 : -1.0;
+            } else if (tc == T - 1 && j == n + row) v = 1.0;        // qp_wrapper.py:669-671
+            P.G[e] = v;
+            continue;
+        }
+        e -= nG;
+        if (e < np) {                                   // p = concat_t c[t,b]
+            const int col = e % nz; const long long b = e / nz;
+            const int t = col / nt, j = col - t * nt;
+            P.p[e] = P.c[((long long)t * B + b) * nt + j];
+            continue;
+        }
+        e -= np;
+        if (e < nb) {                                   // b = [-f ; x0]
+            const int row = e % neq; const long long b = e / neq;
+            const int t = row / n, i = row - t * n;
+            P.b[e] = (t < T - 1) ? -P.f[((long long)t * B + b) * n + i] : P.x0[b * n + i];
+            continue;
+        }
+        e -= nb;
+        {                                               // h = [u_upper ; -u_lower] (or ones)
+            const int row = e % nineq;
+            double v = 1.0;
+            if (P.bounds) {
+                const int k = row < T * m ? row : row - T * m;
+                const int ju = k % m;
+                v = row < T * m ? P.uu[ju] : -P.ul[ju];
+            }
+            P.h[e] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void assemble_backward_kernel(MpcP P)
+{
+    const int n = P.n, m = P.m, T = P.T, nt = n + m, nz = T * nt, neq = T * n;
+    const long long B = P.B;
+    const long long nC = (long long)T * B * nt * nt, nc = (long long)T * B * nt;
+    const long long nF = (long long)(T - 1) * B * n * nt, nf = (long long)(T - 1) * B * n, nx = B * n;
+    const long long total = nC + nc + nF + nf + nx;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        long long e = idx;
+        if (e < nC) {
+            const int j = e % nt; long long q = e / nt;
+            const int i = q % nt; q /= nt;
+            const long long b = q % B; const int t = q / B;
+            if (P.dC) P.dC[e] = P.dQ ? P.dQ[(b * nz + t * nt + i) * nz + t * nt + j] : 0.0;
+            continue;
+        }
+        e -= nC;
+        if (e < nc) {
+            const int j = e % nt; long long q = e / nt;
+            const long long b = q % B; const int t = q / B;
+            if (P.dc) P.dc[e] = P.dp ? P.dp[b * nz + t * nt + j] : 0.0;
+            continue;
+        }
+        e -= nc;
+        if (e < nF) {
+            const int j = e % nt; long long q = e / nt;
+            const int i = q % n; q /= n;
+            const long long b = q % B; const int t = q / B;
+            if (P.dF) P.dF[e] = P.dA ? P.dA[(b * neq + t * n + i) * nz + t * nt + j] : 0.0;
+            continue;
+        }
+        e -= nF;
+        if (e < nf) {
+            const int i = e % n; long long q = e / n;
+            const long long b = q % B; const int t = q / B;
+            if (P.df) P.df[e] = P.db ? -P.db[b * neq + t * n + i] : 0.0;
+            continue;
+        }
+        e -= nf;
+        {
+            const int i = e % n; const long long b = e / n;
+            if (P.dx0) P.dx0[e] = P.db ? P.db[b * neq + (T - 1) * n + i] : 0.0;
+        }
+    }
+}
+
+int check(const dqp_mpc_dims *d)
+{
+    if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2) return DQP_ERR_BAD_ARG;
+    return DQP_OK;
+}
+
+int grid_for(long long total)
+{
+    long long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));     // grid-stride beyond 8 blocks per CU
+}
+
+}  // namespace
+
+extern "C" {
+
+__attribute__((visibility("default"))) int
+dqp_mpc_assemble(const dqp_mpc_dims *d, const double *C, const double *c, const double *F,
+                 const double *f, const double *x0, const double *u_lower, const double *u_upper,
+                 double *Q, double *p, double *G, double *h, double *A, double *b, void *stream)
+{
+    int rc = check(d);
+    if (rc) return rc;
+    if (d->nbatch == 0) return DQP_OK;
+    if (!C || !c || !F || !f || !x0 || !Q || !p || !G || !h || !A || !b) return DQP_ERR_BAD_ARG;
+    if (d->has_bounds && (!u_lower || !u_upper)) return DQP_ERR_BAD_ARG;
+    MpcP P = {};
+    P.C = C; P.c = c; P.F = F; P.f = f; P.x0 = x0; P.ul = u_lower; P.uu = u_upper;
+    P.Q = Q; P.p = p; P.G = G; P.h = h; P.A = A; P.b = b;
+    P.B = d->nbatch; P.n = d->n_state; P.m = d->n_ctrl; P.T = d->T; P.bounds = d->has_bounds;
+    const long long nt = P.n + P.m, nz = P.T * nt, neq = (long long)P.T * P.n;
+    const long long nineq = P.bounds ? 2LL * P.T * P.m : P.m;
+    const long long total = (long long)P.B * (nz * nz + neq * nz + nineq * nz + nz + neq + nineq);
+    hipLaunchKernelGGL(assemble_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+__attribute__((visibility("default"))) int
+dqp_mpc_assemble_backward(const dqp_mpc_dims *d, const double *dQ, const double *dp,
+                          const double *dA, const double *db, double *dC, double *dc, double *dF,
+                          double *df, double *dx0, void *stream)
+{
+    int rc = check(d);
+    if (rc) return rc;
+    if (d->nbatch == 0) return DQP_OK;
+    MpcP P = {};
+    P.dQ = dQ; P.dp = dp; P.dA = dA; P.db = db;
+    P.dC = dC; P.dc = dc; P.dF = dF; P.df = df; P.dx0 = dx0;
+    P.B = d->nbatch; P.n = d->n_state; P.m = d->n_ctrl; P.T = d->T; P.bounds = d->has_bounds;
+    const long long nt = P.n + P.m;
+    const long long total = (long long)P.B * (P.T * nt * nt + P.T * nt + (P.T - 1) * P.n * nt +
+                                              (P.T - 1) * P.n + P.n);
+    hipLaunchKernelGGL(assemble_backward_kernel, dim3(grid_for(total)), dim3(256), 0,
+                       (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+}  // extern "C"

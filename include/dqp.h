@@ -119,6 +119,38 @@ int dqp_qp_backward(const dqp_dims *dims, const dqp_opts *opts,
                     double *dQ, double *dp, double *dG, double *dh, double *dA, double *db,
                     int32_t *info, void *workspace, void *stream);
 
+/* ------------------------------------------------------------------ MPC-structured QPs */
+
+typedef struct dqp_mpc_dims {
+    int32_t nbatch;
+    int32_t n_state;
+    int32_t n_ctrl;
+    int32_t T;            /* horizon; nz = T (n_state+n_ctrl), neq = T n_state                */
+    int32_t has_bounds;   /* 1: nineq = 2 T n_ctrl (box on u); 0: nineq = n_ctrl placeholder  */
+    int32_t reserved;
+} dqp_mpc_dims;
+
+/*
+ * Replaces: qp_wrapper.MPC.compute_Qq_dense / compute_Ab_dense / compute_Gh_dense
+ *           (qpth/qp_wrapper.py:638-679) as called from single_qp (qp_wrapper.py:311-313).
+ * Inputs are the reference's time-major tensors C (T,B,nt,nt) c (T,B,nt) F (T-1,B,n,nt)
+ * f (T-1,B,n) x0 (B,n) and the control bounds u_lower/u_upper (n_ctrl,) (ignored without
+ * bounds).  Outputs are the dense batch-major QP (Q,p,G,h,A,b) that dqp_qp_forward consumes.
+ */
+int dqp_mpc_assemble(const dqp_mpc_dims *dims, const double *C, const double *c, const double *F,
+                     const double *f, const double *x0, const double *u_lower,
+                     const double *u_upper, double *Q, double *p, double *G, double *h,
+                     double *A, double *b, void *stream);
+
+/*
+ * Adjoint of dqp_mpc_assemble (what autograd derives from the index scatters of
+ * qp_wrapper.py:644-679): gathers dC,dc,dF,df,dx0 from dQ,dp,dA,db.  Any pointer may be NULL
+ * (missing inputs read as zero, missing outputs are skipped).
+ */
+int dqp_mpc_assemble_backward(const dqp_mpc_dims *dims, const double *dQ, const double *dp,
+                              const double *dA, const double *db, double *dC, double *dc,
+                              double *dF, double *df, double *dx0, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

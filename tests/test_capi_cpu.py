@@ -49,6 +49,18 @@ def test_argument_validation_without_gpu(lib):
     assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 14)) == 0    # empty batch: no launch
 
 
+def test_mpc_argument_validation_without_gpu(lib):
+    from diff_qp_mpc_amd import _lib
+    z = ctypes.c_void_p(0)
+    d = _lib.dqp_mpc_dims(4, 3, 3, 1, 1, 0)                       # T < 2
+    assert lib.dqp_mpc_assemble(ctypes.byref(d), *([z] * 14)) == -1
+    d = _lib.dqp_mpc_dims(4, 3, 3, 5, 1, 0)                       # null pointers
+    assert lib.dqp_mpc_assemble(ctypes.byref(d), *([z] * 14)) == -1
+    d = _lib.dqp_mpc_dims(0, 3, 3, 5, 1, 0)                       # empty batch
+    assert lib.dqp_mpc_assemble(ctypes.byref(d), *([z] * 14)) == 0
+    assert lib.dqp_mpc_assemble_backward(ctypes.byref(d), *([z] * 10)) == 0
+
+
 def test_operators_refuse_cpu_tensors():
     import torch
     import diff_qp_mpc_amd as dqp

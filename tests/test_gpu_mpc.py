@@ -1,0 +1,98 @@
+"""GPU parity of the qp_wrapper.MPC row against golden vectors captured
+from the reference's own qp_wrapper.MPC with LinDx dynamics (tests/golden/make_golden.py).
+
+  * assembly (compute_Qq/Ab/Gh_dense): bit-exact (it only moves numbers);
+  * MPC.forward x, u: rtol 1e-6 / atol 1e-8;  gradients wrt C, c, F, f, x0: rtol 1e-4 / atol 1e-6.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = [("M_metric_b8", 3, 3, 5), ("M_pend_shape_b4", 3, 1, 10)]
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+def dev(a, grad=False):
+    t = torch.tensor(np.asarray(a), dtype=torch.float64, device="cuda")
+    return t.requires_grad_() if grad else t
+
+
+@pytest.mark.parametrize("name,n,m,T", CASES)
+def test_assembly_bit_exact(name, n, m, T):
+    from diff_qp_mpc_amd.qp_wrapper import _AssembleDenseQP
+    g = load(name)
+    out = _AssembleDenseQP.apply(dev(g["mpc_C"]), dev(g["mpc_c"]), dev(g["mpc_F"]), dev(g["mpc_f"]),
+                                 dev(g["mpc_x0"]), dev(g["mpc_u_lower"]), dev(g["mpc_u_upper"]), n, m, T)
+    for k, t in zip("QpGhAb", out):
+        assert np.array_equal(t.cpu().numpy(), g["in_" + k]), k
+
+
+@pytest.mark.parametrize("name,n,m,T", CASES)
+def test_assembly_adjoint(name, n, m, T):
+    """The backward kernel is the exact adjoint (a gather) of the assembly scatter."""
+    from diff_qp_mpc_amd.qp_wrapper import _AssembleDenseQP
+    g = load(name)
+    ins = [dev(g["mpc_" + k], grad=True) for k in ("C", "c", "F", "f", "x0")]
+    Q, p, G, h, A, b = _AssembleDenseQP.apply(*ins, dev(g["mpc_u_lower"]), dev(g["mpc_u_upper"]), n, m, T)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    ws = [torch.randn(t.shape, dtype=torch.float64, device="cuda", generator=gen) for t in (Q, p, A, b)]
+    loss = sum((t * w).sum() for t, w in zip((Q, p, A, b), ws))
+    grads = torch.autograd.grad(loss, ins)
+    nt = n + m
+    B = ins[4].shape[0]
+    wQ, wp, wA, wb = [w.cpu().numpy() for w in ws]
+    dC = np.stack([np.stack([wQ[b, t * nt:(t + 1) * nt, t * nt:(t + 1) * nt] for b in range(B)]) for t in range(T)])
+    assert np.array_equal(grads[0].cpu().numpy(), dC)
+    dc = np.stack([wp[:, t * nt:(t + 1) * nt] for t in range(T)])
+    assert np.array_equal(grads[1].cpu().numpy(), dc)
+    dF = np.stack([wA[:, t * n:(t + 1) * n, t * nt:(t + 1) * nt] for t in range(T - 1)])
+    assert np.array_equal(grads[2].cpu().numpy(), dF)
+    df = np.stack([-wb[:, t * n:(t + 1) * n] for t in range(T - 1)])
+    assert np.array_equal(grads[3].cpu().numpy(), df)
+    assert np.array_equal(grads[4].cpu().numpy(), wb[:, (T - 1) * n:])
+
+
+@pytest.mark.parametrize("name,n,m,T", CASES)
+@pytest.mark.parametrize("tag,kw", [("single", dict(single_qp_solve=True)), ("sqp", dict(qp_iter=3))])
+def test_mpc_forward_backward_vs_golden(name, n, m, T, tag, kw):
+    from diff_qp_mpc_amd.qp_wrapper import MPC, QuadCost, LinDx
+    g = load(name)
+    B = g["mpc_x0"].shape[0]
+    C, c, F, f, x0 = [dev(g["mpc_" + k], grad=True) for k in ("C", "c", "F", "f", "x0")]
+    mpc = MPC(n, m, T, u_lower=dev(g["mpc_u_lower"]), u_upper=dev(g["mpc_u_upper"]), n_batch=B,
+              verbose=-1, **kw)
+    x, u = mpc(x0, QuadCost(C, c), LinDx(F, f), None)
+    np.testing.assert_allclose(x.detach().cpu().numpy(), g["mpc_%s_x" % tag], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(u.detach().cpu().numpy(), g["mpc_%s_u" % tag], rtol=1e-6, atol=1e-8)
+    (x.sum() + 2.0 * u.sum()).backward()
+    for k, t in (("C", C), ("c", c), ("F", F), ("f", f), ("x0", x0)):
+        got = t.grad.cpu().numpy() if t.grad is not None else np.zeros(t.shape)
+        np.testing.assert_allclose(got, g["mpc_%s_d%s" % (tag, k)], rtol=1e-4, atol=1e-6,
+                                   err_msg="%s d%s" % (tag, k))
+
+
+def test_mpc_rollout_consistency_full_batch():
+    """B=4096 metric shape: the returned trajectory satisfies the (linear) dynamics and bounds."""
+    from diff_qp_mpc_amd.qp_wrapper import MPC, QuadCost, LinDx
+    n, m, T, B = 3, 3, 5, 4096
+    gen = torch.Generator().manual_seed(42)
+    Ad = torch.eye(n, dtype=torch.float64) + 0.2 * torch.randn(n, n, generator=gen, dtype=torch.float64)
+    Bd = torch.randn(n, m, generator=gen, dtype=torch.float64)
+    C = torch.eye(n + m, dtype=torch.float64).repeat(T, B, 1, 1).cuda()
+    c = torch.randn(T, B, n + m, generator=gen, dtype=torch.float64).cuda()
+    x0 = torch.randn(B, n, generator=gen, dtype=torch.float64).cuda()
+    F = torch.cat([Ad, Bd], 1).repeat(T - 1, B, 1, 1).cuda()
+    f = torch.zeros(T - 1, B, n, dtype=torch.float64).cuda()
+    one = torch.ones(m, dtype=torch.float64).cuda()
+    mpc = MPC(n, m, T, u_lower=-one, u_upper=one, n_batch=B, verbose=-1, single_qp_solve=True)
+    x, u = mpc(x0, QuadCost(C, c), LinDx(F, f), None)
+    assert float(u.abs().max()) <= 1.0 + 1e-9
+    xr = mpc.rollout(x0, u, LinDx(F, f))
+    assert float((xr - x).abs().max()) < 1e-8
