@@ -943,23 +943,36 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P)
         for (int s = 0; s < SE; ++s)
             if (P.db && inE[s]) P.db[qp * E + r + 16 * s] = -dyt[s];
     }
+    // Outer products with lanes along the contiguous column axis: for row i the 16 lanes of the
+    // QP's DPP row write 16 consecutive doubles (one 128-byte segment) per slot.
+    if (P.dQ) {
+        double *o = P.dQ + qp * N * N;
 #pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const double zj = BC(zh, j), dxj = BC(dxh, j);
-        if (P.dQ) {
+        for (int i = 0; i < N; ++i) {
+            const double dxi = BC(dxh, i), zi = BC(zh, i);
 #pragma unroll
             for (int s = 0; s < SN; ++s)
-                if (inN[s]) P.dQ[(qp * N + r + 16 * s) * N + j] = 0.5 * (dxh[s] * zj + zh[s] * dxj);
+                if (inN[s]) o[i * N + r + 16 * s] = 0.5 * (dxi * zh[s] + zi * dxh[s]);
         }
-        if (P.dG) {
+    }
+    if (P.dG) {
+        double *o = P.dG + qp * M * N;
 #pragma unroll
-            for (int s = 0; s < SM; ++s)
-                if (inM[s]) P.dG[(qp * M + r + 16 * s) * N + j] = dlam[s] * zj + lam[s] * dxj;
+        for (int i = 0; i < M; ++i) {
+            const double dli = BC(dlam, i), li = BC(lam, i);
+#pragma unroll
+            for (int s = 0; s < SN; ++s)
+                if (inN[s]) o[i * N + r + 16 * s] = dli * zh[s] + li * dxh[s];
         }
-        if (P.dA && E > 0) {
+    }
+    if (P.dA && E > 0) {
+        double *o = P.dA + qp * E * N;
 #pragma unroll
-            for (int s = 0; s < SE; ++s)
-                if (inE[s]) P.dA[(qp * E + r + 16 * s) * N + j] = dyt[s] * zj + nu[s] * dxj;
+        for (int i = 0; i < E; ++i) {
+            const double dni = BC(dyt, i), ni = BC(nu, i);
+#pragma unroll
+            for (int s = 0; s < SN; ++s)
+                if (inN[s]) o[i * N + r + 16 * s] = dni * zh[s] + ni * dxh[s];
         }
     }
     if (r == 0 && P.info) { P.info[2 * qp] = st.status; P.info[2 * qp + 1] = 0; }
