@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libdqp_hip.so")
-SOURCES = ["dqp_pdipm.hip", "dqp_r16.hip", "dqp_mpc.hip"]
+SOURCES = ["dqp_pdipm.hip", "dqp_r16.hip", "dqp_r16n.hip", "dqp_mpc.hip"]
 ARCH = "gfx950"
 
 

@@ -690,7 +690,11 @@ dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, cons
     P.zhat = zhat; P.lam = lam; P.nu = nu; P.slack = slack;
     P.info = info; P.best_resid = best_resid;
     if (!(P.flags & DQP_FLAG_GENERIC_ONLY)) {
-        rc = r16_forward(P, stream);      // DPP-row kernels for the instantiated sizes
+        // DPP-row kernels for the instantiated sizes.  The reduced-Hessian variant is ~2x
+        // faster per iteration but, like every normal-equations IPM, recovers dz = -z - d ds by
+        // cancellation and stalls near 1e-5 on zhat: opt-in only, never the parity path.
+        rc = (P.flags & DQP_FLAG_REDUCED_HESSIAN) ? r16n_forward(P, stream) : 1;
+        if (rc == 1) rc = r16_forward(P, stream);
         if (rc != 1) return rc;
     }
     const int mx = P.N > P.M ? (P.N > P.E ? P.N : P.E) : (P.M > P.E ? P.M : P.E);
@@ -718,6 +722,9 @@ dqp_qp_backward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, con
     P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db;
     P.info = info;
     if (!(P.flags & DQP_FLAG_GENERIC_ONLY)) {
+        // Backward is ONE solve: the Schur-complement form (T = R + D^-1) keeps
+        // dlam accurate for strongly active constraints (d ~ 1e8 after the reference's clamps),
+        // where the reduced-Hessian form loses ~1e-6 to cancellation, so it is used here.
         rc = r16_backward(P, stream);
         if (rc != 1) return rc;
     }

@@ -21,364 +21,10 @@
 //
 // Reference functions covered: as dqp_pdipm.hip.
 
-#include <hip/hip_runtime.h>
-#include <math.h>
-
-#include "dqp_common.h"
+#include "dqp_r16_prims.h"
 
 namespace dqp {
 namespace r16 {
-
-// ------------------------------------------------------------------ cross-lane primitives
-template <int CTRL> __device__ __forceinline__ double dppd(double v)
-{
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true);
-}
-
-// value of lane k (0..15) of each DPP row, in every lane of that row.  k folds to a constant
-// after unrolling, leaving a single v_mov_b64_dpp row_newbcast:k.
-__device__ __forceinline__ double rb(double v, int k)
-{
-    switch (k & 15) {
-    case 0: return dppd<0x150>(v);   case 1: return dppd<0x151>(v);
-    case 2: return dppd<0x152>(v);   case 3: return dppd<0x153>(v);
-    case 4: return dppd<0x154>(v);   case 5: return dppd<0x155>(v);
-    case 6: return dppd<0x156>(v);   case 7: return dppd<0x157>(v);
-    case 8: return dppd<0x158>(v);   case 9: return dppd<0x159>(v);
-    case 10: return dppd<0x15a>(v);  case 11: return dppd<0x15b>(v);
-    case 12: return dppd<0x15c>(v);  case 13: return dppd<0x15d>(v);
-    case 14: return dppd<0x15e>(v);  default: return dppd<0x15f>(v);
-    }
-}
-#define BC(vec, k) rb((vec)[(k) >> 4], (k) & 15)   /* element k of a distributed vector */
-
-__device__ __forceinline__ double row_sum(double v)
-{
-    v += dppd<0x128>(v); v += dppd<0x124>(v); v += dppd<0x122>(v); v += dppd<0x121>(v);
-    return v;
-}
-__device__ __forceinline__ double row_min(double v)
-{
-    v = fmin(v, dppd<0x128>(v)); v = fmin(v, dppd<0x124>(v));
-    v = fmin(v, dppd<0x122>(v)); v = fmin(v, dppd<0x121>(v));
-    return v;
-}
-
-// full-precision reciprocal / reciprocal square root from the hardware estimates + 2 Newton steps
-__device__ __forceinline__ double frcp(double d)
-{
-    double r = __builtin_amdgcn_rcp(d);
-    r = fma(fma(-d, r, 1.0), r, r);
-    r = fma(fma(-d, r, 1.0), r, r);
-    return r;
-}
-__device__ __forceinline__ double frsqrt(double d)
-{
-    double y = __builtin_amdgcn_rsq(d);
-    y = y * fma(-0.5 * d * y, y, 1.5);
-    y = y * fma(-0.5 * d * y, y, 1.5);
-    return y;
-}
-
-// Diagnostic phase stamps: compiled in only with -DDQP_STAMPS (tools/stamps.py builds that
-// variant itself).  Even a never-taken stamp branch perturbs register allocation of the
-// fully unrolled kernels by 2-3x, so the shipped build contains none.
-#ifndef DQP_STAMPS
-#define STAMP(P, i) do { } while (0)
-#else
-#define STAMP(P, i)                                                                  \
-    do {                                                                             \
-        if ((P).stamps) {                                                            \
-            __builtin_amdgcn_sched_barrier(0);                                       \
-            const unsigned long long t__ = __builtin_readcyclecounter();             \
-            if (threadIdx.x == 0) (P).stamps[blockIdx.x * 16 + (i)] = t__;           \
-            __builtin_amdgcn_sched_barrier(0);                                       \
-        }                                                                            \
-    } while (0)
-#endif
-
-constexpr __host__ __device__ int slots(int n) { return (n + 15) / 16; }
-constexpr __host__ __device__ int tri(int i) { return i * (i + 1) / 2; }
-
-// ------------------------------------------------------------------ mat-vec building blocks
-// y[s] (+)= sum_j M[s][j] * x_j          (M row-distributed SR x NC, x distributed length NC)
-template <int SR, int NC, int SX>
-__device__ __forceinline__ void mv_nat(const double (&Mx)[SR][NC], const double (&x)[SX],
-                                       double (&y)[SR], bool accumulate)
-{
-    if (!accumulate) {
-#pragma unroll
-        for (int s = 0; s < SR; ++s) y[s] = 0.0;
-    }
-#pragma unroll
-    for (int j = 0; j < NC; ++j) {
-        const double xb = BC(x, j);
-#pragma unroll
-        for (int s = 0; s < SR; ++s) y[s] = fma(Mx[s][j], xb, y[s]);
-    }
-}
-
-// Reduce-scatter over the 16 lanes of a DPP row: on entry every lane holds its partials v[k]
-// of 16 column sums; the return value on lane k is the total of column k.  Four mirror
-// butterflies (row_mirror, row_half_mirror, quad reverse, quad swap) halve the live values.
-__device__ __forceinline__ double reduce_scatter16(const double (&v)[16], int r)
-{
-    const bool h8 = (r & 8) != 0, h4 = (r & 4) != 0, h2 = (r & 2) != 0, h1 = (r & 1) != 0;
-    double a[8], b4[4], c2[2];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const double keep = h8 ? v[k + 8] : v[k], send = h8 ? v[k] : v[k + 8];
-        a[k] = keep + dppd<0x140>(send);                 // row_mirror: l <-> 15-l
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const double keep = h4 ? a[k + 4] : a[k], send = h4 ? a[k] : a[k + 4];
-        b4[k] = keep + dppd<0x141>(send);                // row_half_mirror: l <-> 7-l
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const double keep = h2 ? b4[k + 2] : b4[k], send = h2 ? b4[k] : b4[k + 2];
-        c2[k] = keep + dppd<0x1b>(send);                 // quad_perm [3,2,1,0]
-    }
-    const double keep = h1 ? c2[1] : c2[0], send = h1 ? c2[0] : c2[1];
-    return keep + dppd<0xb1>(send);                      // quad_perm [1,0,3,2]
-}
-
-// y = M^T v   (M row-distributed SR x NC, v distributed over the rows; y distributed length NC)
-template <int SR, int NC, int SY>
-__device__ __forceinline__ void mv_tr(const double (&Mx)[SR][NC], const double (&v)[SR],
-                                      double (&y)[SY], int r)
-{
-#pragma unroll
-    for (int g = 0; g < SY; ++g) {
-        double p[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int c = 16 * g + k;
-            if (c < NC) {
-                double a = Mx[0][c < NC ? c : 0] * v[0];
-#pragma unroll
-                for (int s = 1; s < SR; ++s) a = fma(Mx[s][c < NC ? c : 0], v[s], a);
-                p[k] = a;
-            } else {
-                p[k] = 0.0;
-            }
-        }
-        y[g] = reduce_scatter16(p, r);
-    }
-}
-
-// ------------------------------------------------------------------ factorizations in registers
-// Lower Cholesky of the row-distributed SPD matrix (in place; strict upper part zeroed).
-// rd[s] = 1/L[i][i] for the lane's rows.  Returns false on a non-positive pivot.
-template <int S, int N>
-__device__ __forceinline__ bool chol_rows(double (&L)[S][N], double (&rd)[S], int r)
-{
-    bool ok = true;
-#pragma unroll
-    for (int s = 0; s < S; ++s) rd[s] = 0.0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int sk = k >> 4, lk = k & 15;
-        double dk = rb(L[sk][k], lk);
-        if (!(dk > 0.0)) { ok = false; dk = 1.0; }
-        const double ri = frsqrt(dk);
-        if (r == lk) rd[sk] = ri;
-        double col[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (16 * s + 15 < k) col[s] = 0.0;                              // rows all above k
-            else if (16 * s >= k) col[s] = L[s][k] * ri;                    // rows all >= k
-            else col[s] = (r >= lk) ? L[s][k] * ri : 0.0;
-            L[s][k] = col[s];
-        }
-#pragma unroll
-        for (int j = k + 1; j < N; ++j) {
-            const double cj = BC(col, j);
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-                if (16 * s + 15 >= j) L[s][j] = fma(-col[s], cj, L[s][j]);   // only rows i >= j matter
-        }
-    }
-    return ok;
-}
-
-// Unpivoted LU of the row-distributed matrix (in place: unit-lower multipliers below the
-// diagonal, U on/above).  rdu[s] = 1/U[i][i].
-template <int S, int N>
-__device__ __forceinline__ void lu_rows(double (&T)[S][N], double (&rdu)[S], int r)
-{
-#pragma unroll
-    for (int s = 0; s < S; ++s) rdu[s] = 0.0;
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int sk = k >> 4, lk = k & 15;
-        const double rp = frcp(rb(T[sk][k], lk));
-        if (r == lk) rdu[sk] = rp;
-        double l[S];
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (16 * s + 15 <= k) l[s] = 0.0;
-            else if (16 * s > k) { l[s] = T[s][k] * rp; T[s][k] = l[s]; }
-            else { const bool a = r > lk; l[s] = a ? T[s][k] * rp : 0.0; T[s][k] = a ? l[s] : T[s][k]; }
-        }
-#pragma unroll
-        for (int j = k + 1; j < N; ++j) {
-            const double ub = rb(T[sk][j], lk);
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-                if (16 * s + 15 > k) T[s][j] = fma(-l[s], ub, T[s][j]);
-        }
-    }
-}
-
-// b <- T^-1 b with the LU above.
-template <int S, int N>
-__device__ __forceinline__ void lu_solve(const double (&T)[S][N], const double (&rdu)[S],
-                                         double (&b)[S], int r)
-{
-#pragma unroll
-    for (int k = 0; k < N - 1; ++k) {                  // L y = b
-        const int lk = k & 15;
-        const double bk = BC(b, k);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (16 * s + 15 <= k) continue;
-            if (16 * s > k) b[s] = fma(-T[s][k], bk, b[s]);
-            else b[s] = fma(r > lk ? -T[s][k] : 0.0, bk, b[s]);
-        }
-    }
-#pragma unroll
-    for (int k = N - 1; k >= 0; --k) {                 // U x = y
-        const int sk = k >> 4, lk = k & 15;
-        const double xk = rb(b[sk] * rdu[sk], lk);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (16 * s > k) continue;
-            if (16 * s + 15 < k) b[s] = fma(-T[s][k], xk, b[s]);
-            else b[s] = (r == lk) ? xk : fma(r < lk ? -T[s][k] : 0.0, xk, b[s]);
-        }
-    }
-}
-
-// b <- L^-1 b, L lower triangular row-distributed in registers (rd = reciprocal diagonal)
-template <int S, int N>
-__device__ __forceinline__ void trsv_rows(const double (&L)[S][N], const double (&rd)[S],
-                                          double (&b)[S], int r)
-{
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int sk = k >> 4, lk = k & 15;
-        const double yk = rb(b[sk] * rd[sk], lk);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (16 * s + 15 < k) continue;
-            if (16 * s > k) b[s] = fma(-L[s][k], yk, b[s]);
-            else b[s] = (r == lk) ? yk : fma(r > lk ? -L[s][k] : 0.0, yk, b[s]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------ packed-triangle LDS helpers
-// LDS holds, per QP, the packed lower triangle P[tri(i) + j], j <= i.
-template <int S, int N>
-__device__ __forceinline__ void tri_store(double *P, const double (&L)[S][N], int r, double *dummy)
-{
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int i = r + 16 * s;
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            if (j > 16 * s + 15) continue;
-            double *dst = (i < N && j <= i) ? P + tri(i) + j : dummy;
-            *dst = L[s][j];
-        }
-    }
-}
-
-// y = L x with L the packed lower triangle in LDS (x, y distributed length N)
-template <int S, int N>
-__device__ __forceinline__ void tri_mv(const double *P, const double (&x)[S], double (&y)[S], int r)
-{
-#pragma unroll
-    for (int s = 0; s < S; ++s) y[s] = 0.0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        const double xb = BC(x, j);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (16 * s + 15 < j) continue;
-            const int i = r + 16 * s;
-            const int ic = i < N ? i : N - 1;
-            const double v = P[tri(ic) + (j <= ic ? j : 0)];
-            y[s] = fma((j <= i && i < N) ? v : 0.0, xb, y[s]);
-        }
-    }
-}
-
-// b <- L^-1 b with L packed in LDS (forward substitution; rd distributed reciprocal diagonal)
-template <int S, int N>
-__device__ __forceinline__ void tri_solve(const double *P, const double (&rd)[S], double (&b)[S], int r)
-{
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-        const int sk = k >> 4, lk = k & 15;
-        const double yk = rb(b[sk] * rd[sk], lk);
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (16 * s + 15 < k) continue;
-            const int i = r + 16 * s;
-            const int ic = i < N ? i : N - 1;
-            const double v = P[tri(ic) + (k <= ic ? k : 0)];
-            if (16 * s > k) b[s] = fma((i < N) ? -v : 0.0, yk, b[s]);
-            else b[s] = (r == lk) ? yk : fma((r > lk && i < N) ? -v : 0.0, yk, b[s]);
-        }
-    }
-}
-
-// b <- L^-T b with L packed in LDS: x_j = (b_j - sum_{i>j} L[i][j] x_i) / L[j][j]; the sum over
-// rows is a row reduction (the transposed access pattern of row-distributed storage).
-template <int S, int N>
-__device__ __forceinline__ void tri_solve_T(const double *P, const double (&rd)[S], double (&b)[S], int r)
-{
-#pragma unroll
-    for (int j = N - 1; j >= 0; --j) {
-        const int sj = j >> 4, lj = j & 15;
-        double part = 0.0;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            if (16 * s + 15 <= j) continue;
-            const int i = r + 16 * s;
-            const int ic = i < N ? i : N - 1;
-            const double v = P[tri(ic) + (j <= ic ? j : 0)];
-            part = fma((i > j && i < N) ? v : 0.0, b[s], part);
-        }
-        const double tot = row_sum(part);
-        if (r == lj) b[sj] = (b[sj] - tot) * rd[sj];
-    }
-}
-
-// distributed vector <-> LDS (each lane touches only its own elements: no barrier needed)
-template <int S>
-__device__ __forceinline__ void vec_put(double *P, const double (&v)[S], int n, int r, double *dummy)
-{
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int i = r + 16 * s;
-        double *dst = i < n ? P + i : dummy;
-        *dst = v[s];
-    }
-}
-template <int S>
-__device__ __forceinline__ void vec_get(const double *P, double (&v)[S], int n, int r)
-{
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int i = r + 16 * s;
-        const double x = P[i < n ? i : n - 1];
-        v[s] = i < n ? x : 0.0;
-    }
-}
 
 // ------------------------------------------------------------------ per-size configuration
 template <int N_, int M_, int E_> struct Cfg {
@@ -404,24 +50,6 @@ template <class C> struct State {
     double rd1[C::SE];           // 1 / diag(L1)
     int status;
 };
-
-// Row-distributed load of an nrows x NC matrix (rows beyond nrows are zero).
-template <int S, int NC>
-__device__ __forceinline__ void load_rows(const double *src, int nrows, double (&dst)[S][NC], int r)
-{
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int i = r + 16 * s;
-        const double *row = src + (i < nrows ? i : nrows - 1) * NC;
-        const double keep = i < nrows ? 1.0 : 0.0;
-#pragma unroll
-        for (int j = 0; j < NC; ++j) dst[s][j] = row[j];
-        if (16 * s + 15 >= nrows) {
-#pragma unroll
-            for (int j = 0; j < NC; ++j) dst[s][j] *= keep;
-        }
-    }
-}
 
 // One-time factorisations (reference: pre_factor_kkt, batch.py:377-428), all in registers.
 // Writes packed R, Lq, L1 to this QP's LDS block.  Phases are separated by scheduling
@@ -602,12 +230,12 @@ __device__ __forceinline__ void factor_T(const double *lds, double (&T)[C::SM][C
     lu_rows<SM, M>(T, rdu, r);
 }
 
-// z-part of solve_kkt in hat coordinates (see dqp_pdipm.hip kkt_wz): returns wz in g.
+// Right-hand side of the z-part of solve_kkt in hat coordinates (see dqp_pdipm.hip kkt_wz):
+//   g = rz - rs/d - Gh (rxh - At^T (At rxh - ryt)).   Touches Gh/At only (not T).
 template <class C>
-__device__ __forceinline__ void kkt_wz(const State<C> &st, const double (&T)[C::SM][C::M],
-                                       const double (&rdu)[C::SM], const double (&rxh)[C::SN],
-                                       const double (&rsd)[C::SM], const double (&rz)[C::SM],
-                                       const double (&ryt)[C::SE], double (&wz)[C::SM], int r)
+__device__ __forceinline__ void kkt_rhs(const State<C> &st, const double (&rxh)[C::SN],
+                                        const double (&rsd)[C::SM], const double (&rz)[C::SM],
+                                        const double (&ryt)[C::SE], double (&g)[C::SM], int r)
 {
     double u[C::SN];
 #pragma unroll
@@ -624,8 +252,7 @@ __device__ __forceinline__ void kkt_wz(const State<C> &st, const double (&T)[C::
     double gu[C::SM];
     mv_nat<C::SM, C::N, C::SN>(st.Gh, u, gu, false);
 #pragma unroll
-    for (int s = 0; s < C::SM; ++s) wz[s] = rz[s] - rsd[s] - gu[s];
-    lu_solve<C::SM, C::M>(T, rdu, wz, r);
+    for (int s = 0; s < C::SM; ++s) g[s] = rz[s] - rsd[s] - gu[s];
 }
 
 // x/y-part: dxh = -q + At^T (At q - ryt), dyt = -(At q - ryt), q = rxh + Gh^T wz
@@ -700,8 +327,11 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         for (int s = 0; s < SM; ++s) { one[s] = inM[s] ? 1.0 : 0.0; zero[s] = 0.0; mh[s] = -hh[s]; }
 #pragma unroll
         for (int s = 0; s < SE; ++s) mb[s] = -bt[s];
+        kkt_rhs<C>(st, ph, zero, mh, mb, wz, r);
+        __builtin_amdgcn_sched_barrier(0);
         factor_T<C>(lds, T, one, rdu, r);
-        kkt_wz<C>(st, T, rdu, ph, zero, mh, mb, wz, r);
+        lu_solve<SM, M>(T, rdu, wz, r);
+        __builtin_amdgcn_sched_barrier(0);
         kkt_xy<C>(st, ph, mb, wz, xh, yt, r);
         double ms = INFINITY, mz = INFINITY;
 #pragma unroll
@@ -792,15 +422,17 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
         if (it == 1) STAMP(P, 9);
 
+        // phase 1 (Gh/At live, T dead): affine right-hand side (rs = z => rs/d = s)
+        double dza[SM], dsa[SM];
+        kkt_rhs<C>(st, rxh, s_, rz, ryt, dza, r);
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2 (T live, Gh/At idle): factor + affine and corrector solves   batch.py:110-181
         double dinv[SM];
 #pragma unroll
         for (int s = 0; s < SM; ++s) dinv[s] = inM[s] ? s_[s] / z[s] : 0.0;   // 1/d, d = z/s
         factor_T<C>(lds, T, dinv, rdu, r);
         if (it == 1) STAMP(P, 10);
-
-        // affine direction (rs = z => rs/d = s)                             batch.py:151
-        double dza[SM], dsa[SM];
-        kkt_wz<C>(st, T, rdu, rxh, s_, rz, ryt, dza, r);
+        lu_solve<SM, M>(T, rdu, dza, r);
         double am = INFINITY;
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
@@ -832,6 +464,8 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             ds[s] = dsa[s] + (inM[s] ? (-rsc[s] - dzc[s]) * dinv[s] : 0.0);
             am = fmin(am, fmin(ratio(z[s], dz[s], inM[s]), ratio(s_[s], ds[s], inM[s])));
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 3 (Gh/At live, T dead): x / y part of the combined direction
         double dxh[SN], dyt[SE];
         kkt_xy<C>(st, rxh, ryt, dz, dxh, dyt, r);
         alpha = fmin(0.999 * row_min(am), 1.0);
@@ -916,8 +550,6 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P)
 #pragma unroll
     for (int s = 0; s < SE; ++s) nu[s] = (E > 0 && inE[s]) ? P.nuin[qp * E + r + 16 * s] : 0.0;
 
-    double T[SM][M], rdu[SM];
-    factor_T<C>(lds, T, dinv, rdu, r);
     // solve_kkt(rx = dl_dzhat, 0, 0, 0)
     tri_solve<SN, N>(lds + C::oLq, st.rdq, g, r);                       // rxh = Lq^-1 g
     double zeroM[SM], zeroE[SE], dlam[SM], dxh[SN], dyt[SE];
@@ -925,7 +557,14 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P)
     for (int s = 0; s < SM; ++s) zeroM[s] = 0.0;
 #pragma unroll
     for (int s = 0; s < SE; ++s) zeroE[s] = 0.0;
-    kkt_wz<C>(st, T, rdu, g, zeroM, zeroM, zeroE, dlam, r);
+    kkt_rhs<C>(st, g, zeroM, zeroM, zeroE, dlam, r);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        double T[SM][M], rdu[SM];
+        factor_T<C>(lds, T, dinv, rdu, r);
+        lu_solve<SM, M>(T, rdu, dlam, r);
+    }
+    __builtin_amdgcn_sched_barrier(0);
     kkt_xy<C>(st, g, zeroE, dlam, dxh, dyt, r);
     tri_solve_T<SN, N>(lds + C::oLq, st.rdq, dxh, r);                   // dx = Lq^-T dxh
     if (E > 0) tri_solve_T<SE, C::EC>(lds + C::oL1, st.rd1, dyt, r);    // dnu

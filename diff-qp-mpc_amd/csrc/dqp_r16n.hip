@@ -1,0 +1,885 @@
+// dqp_r16n.hip -- DPP-row kernels, null-space / reduced-Hessian form (4 QPs per wavefront).
+//
+// Same layout idea as dqp_r16.hip (one QP per 16-lane DPP row, matrices row-distributed in
+// registers, v_mov_b64_dpp row_newbcast as the only cross-lane primitive) but the equality
+// constraints are eliminated ONCE, so the per-iteration linear algebra shrinks from the
+// nineq x nineq Schur complement T = R + D^-1 to the (nz-neq) x (nz-neq) reduced Hessian:
+//
+//   hat coordinates   xh = Lq^T x (Q = Lq Lq^T),  Gh = G Lq^-T,  Ah = A Lq^-T
+//   reverse LQ        Ah Qf = [0 | U]   (Householder reflectors H_k, Qf = H_{E-1} ... H_0,
+//                                        U upper triangular E x E in the LAST E columns)
+//   null-space split  xh = Qf [w ; xy],  xy = U^-1 b fixed,  Gh Qf = [Gz | W],  h' = h - W xy
+//   reduced QP        min 1/2 |w|^2 + cp^T w   s.t.  Gz w + s = h',  s >= 0
+//
+// The PDIPM iterates (x, s, z) of the reference (batch.py:46-208) are reproduced exactly in
+// exact arithmetic: Newton's method is affine invariant and, with A x = b holding from the
+// first iterate (batch.py:60-74), (dx, ds, dz) never depend on the equality multipliers y.
+// The y iterate only enters the reference's stopping/selection residual through the range
+// part of rx, which obeys rho_{k+1} = (1 - alpha_k) rho_k; we carry that scalar c_k and
+// reconstruct  ||rx|| = ||(Lq Z) rw + c_k (Lq Y) rho_0||  and  y = U^-T (c rho_0 - xy - py - W^T z).
+// Per iteration:  H = I + Gz^T diag(z/s) Gz  (R x R, R = nz - neq), one unpivoted LU, two
+// solves (affine + corrector), five small mat-vecs.
+//
+// Reference functions covered: a2-a8, a9-a10 of SURVEY.md §8 (as dqp_pdipm.hip / dqp_r16.hip).
+
+#include "dqp_r16_prims.h"
+
+#ifndef DQP_R16N_NREF
+#define DQP_R16N_NREF 1   /* iterative-refinement steps per reduced-Hessian solve */
+#endif
+
+namespace dqp {
+namespace r16n {
+
+using namespace dqp::r16;
+
+template <int N_, int M_, int E_> struct Cfg {
+    static constexpr int N = N_, M = M_, E = E_, R = N_ - E_;
+    static constexpr int SN = slots(N_), SM = slots(M_), SR = slots(N_ - E_);
+    static constexpr int SE = E_ > 0 ? slots(E_) : 1, EC = E_ > 0 ? E_ : 1;
+    // LDS per QP (doubles)
+    static constexpr int tailsz = E_ * (N_ - E_) + E_ * (E_ - 1) / 2;     // sum_k c_k, c_k = R + k
+    static constexpr int oLq = 0;                       // packed lower triangle of Lq
+    static constexpr int oTl = tri(N_);                 // packed reflector tails u'_k[0..c_k)
+    static constexpr int oCp = oTl + tailsz;            // cp (R)
+    static constexpr int oHp = oCp + (N_ - E_);         // h' (M)
+    static constexpr int oQv = oHp + M_;                // qv = Lq Y (W^T 1)  (N)
+    static constexpr int oBw = oQv + N_;                // best w (R), s (M), z (M), c (1)
+    static constexpr int oBs = oBw + (N_ - E_), oBz = oBs + M_, oBc = oBz + M_;
+    static constexpr int oScr = oBc + 2;                // 16 x R transpose scratch
+    static constexpr int oDummy = oScr + 16 * (N_ - E_);
+    static constexpr int ldsQP = oDummy + 16;
+    static constexpr int ldsQPpad = (ldsQP + 1) & ~1;
+    __host__ __device__ static constexpr int toff(int k) { return k * (N_ - E_) + k * (k - 1) / 2; }
+};
+
+template <class C> struct State {
+    double Gh[C::SM][C::N];     // Gh Qf = [Gz | W], row-distributed by constraint
+    double GzT[C::SR][C::M];    // Gz^T, row-distributed by reduced index
+    double LqZ[C::SN][C::R];    // (Lq Qf)[:, :R]
+    double Ah[C::SE][C::N];     // U = Ah[:, R:]  (columns < c_k of row k are dead)
+    double tau[C::SE];          // tau'_k, E-space distributed
+    double rdu1[C::SE];         // 1 / U[k][k]
+    double xy[C::SE];           // U^-1 b
+    double py[C::SE];           // (Qf^T ph)[R:]  in E-space
+    double w1[C::SE];           // W^T 1
+    double rdq[C::SN];
+    int status;
+};
+
+// element R+e of an N-space distributed vector -> element e of an E-space distributed vector
+template <class C>
+__device__ __forceinline__ void shift_down(const double (&vn)[C::SN], double (&ve)[C::SE], int r)
+{
+#pragma unroll
+    for (int s = 0; s < C::SE; ++s) ve[s] = 0.0;
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) {
+        const double t = BC(vn, C::R + e);
+        if (r == (e & 15)) ve[e >> 4] = t;
+    }
+}
+// E-space element e -> N-space position R+e (positions < R untouched)
+template <class C>
+__device__ __forceinline__ void shift_up(const double (&ve)[C::SE], double (&vn)[C::SN], int r)
+{
+#pragma unroll
+    for (int e = 0; e < C::E; ++e) {
+        const double t = BC(ve, e);
+        if (r == ((C::R + e) & 15)) vn[(C::R + e) >> 4] = t;
+    }
+}
+
+// v <- H_k v for one reflector (u'_k read from LDS as a distributed vector)
+template <class C>
+__device__ __forceinline__ void reflect1(const double *lds, const double (&tau)[C::SE],
+                                         double (&v)[C::SN], int k, int r)
+{
+    const int ck = C::R + k;
+    const double *tl = lds + C::oTl + C::toff(k);
+    double ud[C::SN], dot = 0.0;
+#pragma unroll
+    for (int s = 0; s < C::SN; ++s) {
+        if (16 * s > ck) { ud[s] = 0.0; continue; }
+        const int c = r + 16 * s;
+        const double t = tl[c < ck ? c : 0];
+        ud[s] = c < ck ? t : (c == ck ? 1.0 : 0.0);
+        dot = fma(ud[s], v[s], dot);
+    }
+    const double tw = BC(tau, k) * row_sum(dot);
+#pragma unroll
+    for (int s = 0; s < C::SN; ++s)
+        if (16 * s <= ck) v[s] = fma(-tw, ud[s], v[s]);
+}
+// v <- Qf^T v = H_0 ... H_{E-1} v   (H_{E-1} first)
+template <class C>
+__device__ __forceinline__ void apply_QfT(const double *lds, const double (&tau)[C::SE],
+                                          double (&v)[C::SN], int r)
+{
+#pragma unroll
+    for (int k = C::E - 1; k >= 0; --k) reflect1<C>(lds, tau, v, k, r);
+}
+// v <- Qf v = H_{E-1} ... H_0 v   (H_0 first)
+template <class C>
+__device__ __forceinline__ void apply_Qf(const double *lds, const double (&tau)[C::SE],
+                                         double (&v)[C::SN], int r)
+{
+#pragma unroll
+    for (int k = 0; k < C::E; ++k) reflect1<C>(lds, tau, v, k, r);
+}
+
+// t <- U^-T t  (U upper triangular E x E in Ah[:, R:], rows distributed in E-space)
+template <class C>
+__device__ __forceinline__ void solve_UT(const State<C> &st, double (&t)[C::SE], int r)
+{
+#pragma unroll
+    for (int j = 0; j < C::E; ++j) {
+        const int sj = j >> 4, lj = j & 15;
+        double part = 0.0;
+#pragma unroll
+        for (int s = 0; s < C::SE; ++s) {
+            if (16 * s >= j) continue;
+            const int k = r + 16 * s;
+            part = fma(k < j ? st.Ah[s][C::R + j] : 0.0, t[s], part);
+        }
+        const double tot = row_sum(part);
+        if (r == lj) t[sj] = (t[sj] - tot) * st.rdu1[sj];
+    }
+}
+
+// y = Gz v  (v in R-space) -> M-space
+template <class C>
+__device__ __forceinline__ void mul_Gz(const State<C> &st, const double (&v)[C::SR], double (&y)[C::SM])
+{
+#pragma unroll
+    for (int s = 0; s < C::SM; ++s) y[s] = 0.0;
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) {
+        const double vb = BC(v, t);
+#pragma unroll
+        for (int s = 0; s < C::SM; ++s) y[s] = fma(st.Gh[s][t], vb, y[s]);
+    }
+}
+// y = Gz^T v (v in M-space) -> R-space
+template <class C>
+__device__ __forceinline__ void mul_GzT(const State<C> &st, const double (&v)[C::SM], double (&y)[C::SR])
+{
+#pragma unroll
+    for (int s = 0; s < C::SR; ++s) y[s] = 0.0;
+#pragma unroll
+    for (int k = 0; k < C::M; ++k) {
+        const double vb = BC(v, k);
+#pragma unroll
+        for (int s = 0; s < C::SR; ++s) y[s] = fma(st.GzT[s][k], vb, y[s]);
+    }
+}
+// y = W^T v (v in M-space) -> E-space   (transposed product: partials + reduce-scatter)
+template <class C>
+__device__ __forceinline__ void mul_WT(const State<C> &st, const double (&v)[C::SM], double (&y)[C::SE], int r)
+{
+#pragma unroll
+    for (int g = 0; g < C::SE; ++g) {
+        double p[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = 16 * g + k;
+            if (e < C::E) {
+                double a = st.Gh[0][C::R + (e < C::E ? e : 0)] * v[0];
+#pragma unroll
+                for (int s = 1; s < C::SM; ++s) a = fma(st.Gh[s][C::R + (e < C::E ? e : 0)], v[s], a);
+                p[k] = a;
+            } else {
+                p[k] = 0.0;
+            }
+        }
+        y[g] = reduce_scatter16(p, r);
+    }
+}
+
+// H = I + Gz^T diag(d) Gz (R x R, row-distributed in R-space), then unpivoted LU.
+template <class C>
+__device__ __forceinline__ void factor_H(const State<C> &st, const double (&d)[C::SM],
+                                         double (&H)[C::SR][C::R], double (&rdu)[C::SR], int r)
+{
+    constexpr int R = C::R, M = C::M, SR = C::SR;
+#pragma unroll
+    for (int s = 0; s < SR; ++s)
+#pragma unroll
+        for (int j = 0; j < R; ++j) H[s][j] = (r + 16 * s == j) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+        const double dk = BC(d, k);
+        double a[SR];
+#pragma unroll
+        for (int s = 0; s < SR; ++s) a[s] = st.GzT[s][k] * dk;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const double gb = rb(st.GzT[j >> 4][k], j & 15);
+#pragma unroll
+            for (int s = 0; s < SR; ++s) H[s][j] = fma(a[s], gb, H[s][j]);
+        }
+    }
+    // padding rows (index >= R) stay zero except nothing: give them a unit diagonal is not
+    // needed because lu_rows only pivots on k < R.
+    lu_rows<SR, R>(H, rdu, r);
+}
+
+// x <- H^-1 rhs with NREF steps of iterative refinement against the matrix-free operator
+// H x = x + Gz^T (d .* (Gz x)); the LU of the explicitly formed H has a backward error of
+// eps * ||H|| ~ eps * max(d), which refinement removes from the well-conditioned directions.
+template <class C, int NREF>
+__device__ __forceinline__ void solve_H(const State<C> &st, const double (&H)[C::SR][C::R],
+                                        const double (&rdu)[C::SR], const double (&d)[C::SM],
+                                        const double (&rhs)[C::SR], double (&x)[C::SR],
+                                        double (&gx)[C::SM], int r)
+{
+#pragma unroll
+    for (int s = 0; s < C::SR; ++s) x[s] = rhs[s];
+    lu_solve<C::SR, C::R>(H, rdu, x, r);
+    mul_Gz<C>(st, x, gx);
+#pragma unroll
+    for (int it = 0; it < NREF; ++it) {
+        double t[C::SM], res[C::SR];
+#pragma unroll
+        for (int s = 0; s < C::SM; ++s) t[s] = d[s] * gx[s];
+        mul_GzT<C>(st, t, res);
+#pragma unroll
+        for (int s = 0; s < C::SR; ++s) res[s] = (r + 16 * s < C::R) ? rhs[s] - x[s] - res[s] : 0.0;
+        lu_solve<C::SR, C::R>(H, rdu, res, r);
+#pragma unroll
+        for (int s = 0; s < C::SR; ++s) x[s] += res[s];
+        mul_Gz<C>(st, x, gx);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// FWD = false (backward pass): p, h, b are not available (NULL) and xy / cp / h' / LqZ / qv are
+// not needed, so those phases are compiled out.
+template <class C, bool FWD>
+__device__ __forceinline__ void setup(const KParams &P, long long qp, int r, double *lds, State<C> &st)
+{
+    constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
+    constexpr int SN = C::SN, SM = C::SM, SE = C::SE, SR = C::SR;
+    double *dummy = lds + C::oDummy + r;
+    st.status = DQP_STATUS_OK;
+    {   // A: Q -> Lq -> packed LDS
+        double Lq[SN][N];
+        load_rows<SN, N>(P.Q + qp * P.sQ, N, Lq, r);
+        if (!chol_rows<SN, N>(Lq, st.rdq, r)) st.status = DQP_STATUS_Q_NOT_PD;
+        tri_store<SN, N>(lds + C::oLq, Lq, r, dummy);
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // B: rows of G, A times Lq^-T (Lq[j][k] read row-uniformly from LDS)
+    load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
+    if (E > 0) load_rows<SE, N>(P.A + qp * P.sA, E, st.Ah, r);
+    {
+        const double *Lp = lds + C::oLq;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                const double ljk = Lp[tri(j) + k];
+#pragma unroll
+                for (int s = 0; s < SM; ++s) st.Gh[s][j] = fma(-st.Gh[s][k], ljk, st.Gh[s][j]);
+                if (E > 0) {
+#pragma unroll
+                    for (int s = 0; s < SE; ++s) st.Ah[s][j] = fma(-st.Ah[s][k], ljk, st.Ah[s][j]);
+                }
+            }
+            const double rj = BC(st.rdq, j);
+#pragma unroll
+            for (int s = 0; s < SM; ++s) st.Gh[s][j] *= rj;
+            if (E > 0) {
+#pragma unroll
+                for (int s = 0; s < SE; ++s) st.Ah[s][j] *= rj;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+    for (int s = 0; s < SE; ++s) { st.tau[s] = 0.0; st.rdu1[s] = 0.0; st.xy[s] = 0.0; st.py[s] = 0.0; st.w1[s] = 0.0; }
+
+    if (E > 0) {
+        // C: reverse Householder LQ of Ah; reflectors applied to the rows of Ah (above k) and Gh
+#pragma unroll
+        for (int k = E - 1; k >= 0; --k) {
+            const int sk = k >> 4, lk = k & 15, ck = R + k;
+            double u[N];
+            double nrm2 = 0.0;
+#pragma unroll
+            for (int c = 0; c <= ck; ++c) {
+                u[c] = rb(st.Ah[sk][c], lk);
+                nrm2 = fma(u[c], u[c], nrm2);
+            }
+            if (!(nrm2 > 0.0)) { if (st.status == DQP_STATUS_OK) st.status = DQP_STATUS_A_RANK_DEF; nrm2 = 1.0; }
+            const double vk = u[ck];
+            const double alpha = -copysign(sqrt(nrm2), vk);
+            const double uck = vk - alpha;
+            const double iu = frcp(uck);
+            const double tauk = uck * uck * frcp(nrm2 - alpha * vk);
+            double *tl = lds + C::oTl + C::toff(k);
+#pragma unroll
+            for (int c = 0; c < ck; ++c) {
+                u[c] *= iu;
+                double *dst = (r == 0) ? tl + c : dummy;
+                *dst = u[c];
+            }
+            if (r == lk) { st.tau[sk] = tauk; st.rdu1[sk] = frcp(alpha); }
+            // rows of Ah above k
+#pragma unroll
+            for (int s = 0; s < SE; ++s) {
+                if (16 * s > k) continue;
+                double w = st.Ah[s][ck];
+#pragma unroll
+                for (int c = 0; c < ck; ++c) w = fma(st.Ah[s][c], u[c], w);
+                double tw = tauk * w;
+                if (16 * s + 15 >= k) tw = (r + 16 * s < k) ? tw : 0.0;
+#pragma unroll
+                for (int c = 0; c < ck; ++c) st.Ah[s][c] = fma(-tw, u[c], st.Ah[s][c]);
+                st.Ah[s][ck] -= tw;
+            }
+            if (r == lk) st.Ah[sk][ck] = alpha;
+            // rows of Gh
+#pragma unroll
+            for (int s = 0; s < SM; ++s) {
+                double w = st.Gh[s][ck];
+#pragma unroll
+                for (int c = 0; c < ck; ++c) w = fma(st.Gh[s][c], u[c], w);
+                const double tw = tauk * w;
+#pragma unroll
+                for (int c = 0; c < ck; ++c) st.Gh[s][c] = fma(-tw, u[c], st.Gh[s][c]);
+                st.Gh[s][ck] -= tw;
+            }
+        }
+        __syncthreads();          // tails are read back as distributed vectors
+        __builtin_amdgcn_sched_barrier(0);
+
+        // D: xy = U^-1 b
+        if (FWD) {
+            double b[SE];
+#pragma unroll
+            for (int s = 0; s < SE; ++s) b[s] = (r + 16 * s < E) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
+#pragma unroll
+            for (int j = E - 1; j >= 0; --j) {
+                const int sj = j >> 4, lj = j & 15;
+                const double xj = rb(b[sj] * st.rdu1[sj], lj);
+#pragma unroll
+                for (int s = 0; s < SE; ++s) {
+                    if (16 * s > j) continue;
+                    const int k = r + 16 * s;
+                    b[s] = (k == j) ? xj : fma(k < j ? -st.Ah[s][R + j] : 0.0, xj, b[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < SE; ++s) st.xy[s] = b[s];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (FWD) {   // E: ph = Lq^-1 p ; [cp ; py] = Qf^T ph
+        double ph[SN];
+#pragma unroll
+        for (int s = 0; s < SN; ++s) ph[s] = (r + 16 * s < N) ? P.p[qp * P.sp + r + 16 * s] : 0.0;
+        tri_solve<SN, N>(lds + C::oLq, st.rdq, ph, r);
+        if (E > 0) {
+            apply_QfT<C>(lds, st.tau, ph, r);
+            shift_down<C>(ph, st.py, r);
+        }
+        // cp = first R entries
+#pragma unroll
+        for (int s = 0; s < SN; ++s) {
+            const int i = r + 16 * s;
+            double *dst = i < R ? lds + C::oCp + i : dummy;
+            *dst = ph[s];
+        }
+    }
+    if (FWD) {   // F: h' = h - W xy ;  w1 = W^T 1
+        double hp[SM];
+#pragma unroll
+        for (int s = 0; s < SM; ++s) hp[s] = (r + 16 * s < M) ? P.h[qp * P.sh + r + 16 * s] : 0.0;
+        if (E > 0) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double xb = BC(st.xy, e);
+#pragma unroll
+                for (int s = 0; s < SM; ++s) hp[s] = fma(-st.Gh[s][R + e], xb, hp[s]);
+            }
+            double one[SM];
+#pragma unroll
+            for (int s = 0; s < SM; ++s) one[s] = (r + 16 * s < M) ? 1.0 : 0.0;
+            mul_WT<C>(st, one, st.w1, r);
+        }
+        vec_put<SM>(lds + C::oHp, hp, M, r, dummy);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (FWD) {   // G: LqZ = (Lq Qf)[:, :R] ;  qv = (Lq Qf)[:, R:] w1
+        double Ld[SN][N];
+        const double *Lp = lds + C::oLq;
+#pragma unroll
+        for (int s = 0; s < SN; ++s) {
+            const int i = r + 16 * s, ic = i < N ? i : N - 1;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (j > 16 * s + 15) { Ld[s][j] = 0.0; continue; }
+                const double v = Lp[tri(ic) + (j <= ic ? j : 0)];
+                Ld[s][j] = (j <= i && i < N) ? v : 0.0;
+            }
+        }
+        if (E > 0) {
+#pragma unroll
+            for (int k = E - 1; k >= 0; --k) {
+                const int ck = R + k;
+                const double *tl = lds + C::oTl + C::toff(k);
+                const double tauk = BC(st.tau, k);
+                double w[SN];
+#pragma unroll
+                for (int s = 0; s < SN; ++s) w[s] = Ld[s][ck];
+#pragma unroll
+                for (int c = 0; c < ck; ++c) {
+                    const double uc = tl[c];
+#pragma unroll
+                    for (int s = 0; s < SN; ++s) w[s] = fma(Ld[s][c], uc, w[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < SN; ++s) { w[s] *= tauk; Ld[s][ck] -= w[s]; }
+#pragma unroll
+                for (int c = 0; c < ck; ++c) {
+                    const double uc = tl[c];
+#pragma unroll
+                    for (int s = 0; s < SN; ++s) Ld[s][c] = fma(-w[s], uc, Ld[s][c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SN; ++s)
+#pragma unroll
+            for (int t = 0; t < R; ++t) st.LqZ[s][t] = Ld[s][t];
+        double qv[SN];
+#pragma unroll
+        for (int s = 0; s < SN; ++s) qv[s] = 0.0;
+        if (E > 0) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double wb = BC(st.w1, e);
+#pragma unroll
+                for (int s = 0; s < SN; ++s) qv[s] = fma(Ld[s][R + e], wb, qv[s]);
+            }
+        }
+        vec_put<SN>(lds + C::oQv, qv, N, r, dummy);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // H: GzT via a two-pass LDS transpose (16 constraint rows at a time)
+    {
+        double *scr = lds + C::oScr;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < R; ++t) scr[r * R + t] = st.Gh[s][t];
+            __syncthreads();
+#pragma unroll
+            for (int sr = 0; sr < SR; ++sr) {
+                const int t = r + 16 * sr, tc = t < R ? t : R - 1;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int k = 16 * s + kk;
+                    if (k < M) {
+                        const double v = scr[kk * R + tc];
+                        st.GzT[sr][k < M ? k : 0] = (t < R) ? v : 0.0;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ double ratio(double v, double dv, bool active)
+{
+    return (active && dv < 0.0) ? -v / dv : INFINITY;
+}
+
+// y = LqZ v + cc * qv   (N-space), returns sum of squares partial (lane-local)
+template <class C>
+__device__ __forceinline__ double rx_norm2_partial(const State<C> &st, const double *lds,
+                                                   const double (&rw)[C::SR], double cc, int r)
+{
+    double rx[C::SN];
+    vec_get<C::SN>(lds + C::oQv, rx, C::N, r);
+#pragma unroll
+    for (int s = 0; s < C::SN; ++s) rx[s] *= cc;
+#pragma unroll
+    for (int t = 0; t < C::R; ++t) {
+        const double vb = BC(rw, t);
+#pragma unroll
+        for (int s = 0; s < C::SN; ++s) rx[s] = fma(st.LqZ[s][t], vb, rx[s]);
+    }
+    double a = 0.0;
+#pragma unroll
+    for (int s = 0; s < C::SN; ++s) a = fma(rx[s], rx[s], a);
+    return a;
+}
+
+template <class C>
+__global__ __launch_bounds__(64) void forward_kernel(KParams P)
+{
+    constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
+    constexpr int SN = C::SN, SM = C::SM, SE = C::SE, SR = C::SR;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
+    long long qp = (long long)blockIdx.x * 4 + qrow;
+    const bool live = qp < P.B;
+    if (!live) qp = P.B - 1;
+    double *lds = sm + qrow * C::ldsQPpad;
+    double *dummy = lds + C::oDummy + r;
+
+    State<C> st;
+    setup<C, true>(P, qp, r, lds, st);
+
+    bool inM[SM], inR[SR];
+#pragma unroll
+    for (int s = 0; s < SM; ++s) inM[s] = r + 16 * s < M;
+#pragma unroll
+    for (int s = 0; s < SR; ++s) inR[s] = r + 16 * s < R;
+
+    double H[SR][R], rdu[SR];
+    double w[SR], s_[SM], z[SM], gw[SM];
+    double cc = 1.0, delta = 0.0;
+    {   // initial point (batch.py:60-86):  (I + Gz^T Gz) w = Gz^T h' - cp ;  z = Gz w - h' ; s = -z
+        double one[SM], hp[SM], cp[SR], rhs[SR];
+#pragma unroll
+        for (int s = 0; s < SM; ++s) one[s] = inM[s] ? 1.0 : 0.0;
+        factor_H<C>(st, one, H, rdu, r);
+        vec_get<SM>(lds + C::oHp, hp, M, r);
+        vec_get<SR>(lds + C::oCp, cp, R, r);
+        mul_GzT<C>(st, hp, rhs);
+#pragma unroll
+        for (int s = 0; s < SR; ++s) w[s] = inR[s] ? rhs[s] - cp[s] : 0.0;
+        lu_solve<SR, R>(H, rdu, w, r);
+        mul_Gz<C>(st, w, gw);
+        double ms = INFINITY, mz = INFINITY;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            z[s] = inM[s] ? gw[s] - hp[s] : 0.0;
+            s_[s] = -z[s];
+            ms = fmin(ms, inM[s] ? s_[s] : INFINITY);
+            mz = fmin(mz, inM[s] ? z[s] : INFINITY);
+        }
+        ms = row_min(ms); mz = row_min(mz);
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            if (ms < 0.0 && inM[s]) s_[s] -= ms - 1.0;
+            if (mz < 0.0 && inM[s]) z[s] -= mz - 1.0;
+        }
+        delta = mz < 0.0 ? 1.0 - mz : 0.0;        // rho_0 = delta * W^T 1
+    }
+
+    double best = INFINITY, bestc = 1.0;
+    bool have_best = false, done = false;
+    int nNot = 0, iters = 0;
+
+    for (int it = 0; it < P.maxIter; ++it) {
+        double rw[SR], rz[SM];
+        {
+            double cp[SR], hp[SM];
+            mul_GzT<C>(st, z, rw);
+            vec_get<SR>(lds + C::oCp, cp, R, r);
+            vec_get<SM>(lds + C::oHp, hp, M, r);
+#pragma unroll
+            for (int s = 0; s < SR; ++s) rw[s] = inR[s] ? rw[s] + w[s] + cp[s] : 0.0;
+#pragma unroll
+            for (int s = 0; s < SM; ++s) rz[s] = inM[s] ? gw[s] + s_[s] - hp[s] : 0.0;
+        }
+        double sz = 0.0, nz2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) { sz = fma(s_[s], z[s], sz); nz2 = fma(rz[s], rz[s], nz2); }
+        double nx2 = rx_norm2_partial<C>(st, lds, rw, cc * delta, r);
+        sz = row_sum(sz); nz2 = row_sum(nz2); nx2 = row_sum(nx2);
+        const double mu = fabs(sz / M);
+        const double resid = sqrt(nz2) + sqrt(nx2) + M * mu;
+        if (!done) {
+            iters = it + 1;
+            if (!have_best || resid < best) {
+                nNot = 0; have_best = true; best = resid; bestc = cc;
+                vec_put<SR>(lds + C::oBw, w, R, r, dummy);
+                vec_put<SM>(lds + C::oBs, s_, M, r, dummy);
+                vec_put<SM>(lds + C::oBz, z, M, r, dummy);
+            } else {
+                nNot += 1;
+            }
+            if ((nNot >= P.notImprovedLim && best < P.stallTol) || best < P.eps || mu > 1e32 ||
+                !(fabs(resid) < INFINITY))
+                done = true;
+        }
+        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+
+        double d[SM];
+#pragma unroll
+        for (int s = 0; s < SM; ++s) d[s] = inM[s] ? z[s] / s_[s] : 0.0;
+        factor_H<C>(st, d, H, rdu, r);
+
+        // affine: H dw = -rw + Gz^T (z - d rz);  ds = -rz - Gz dw;  dz = -z - d ds
+        double tmpM[SM], dwa[SR], gda[SM], dsa[SM], dza[SM];
+#pragma unroll
+        for (int s = 0; s < SM; ++s) tmpM[s] = inM[s] ? z[s] - d[s] * rz[s] : 0.0;
+        {
+            double rhs[SR];
+            mul_GzT<C>(st, tmpM, rhs);
+#pragma unroll
+            for (int s = 0; s < SR; ++s) rhs[s] = inR[s] ? rhs[s] - rw[s] : 0.0;
+            solve_H<C, DQP_R16N_NREF>(st, H, rdu, d, rhs, dwa, gda, r);
+        }
+        double am = INFINITY;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            dsa[s] = inM[s] ? -rz[s] - gda[s] : 0.0;
+            dza[s] = inM[s] ? -z[s] - d[s] * dsa[s] : 0.0;
+            am = fmin(am, fmin(ratio(z[s], dza[s], inM[s]), ratio(s_[s], dsa[s], inM[s])));
+        }
+        double alpha = fmin(row_min(am), 1.0);
+        double t3 = 0.0;
+#pragma unroll
+        for (int s = 0; s < SM; ++s)
+            t3 += inM[s] ? (s_[s] + alpha * dsa[s]) * (z[s] + alpha * dza[s]) : 0.0;
+        t3 = row_sum(t3);
+        double sig = t3 / sz;
+        sig = sig * sig * sig;
+        // corrector: rs = (-mu sig + ds_a dz_a)/s, rw = rz = 0
+        double rsc[SM], dwc[SR], gdc[SM];
+#pragma unroll
+        for (int s = 0; s < SM; ++s) rsc[s] = inM[s] ? (-mu * sig + dsa[s] * dza[s]) / s_[s] : 0.0;
+        {
+            double rhs[SR];
+            mul_GzT<C>(st, rsc, rhs);
+#pragma unroll
+            for (int s = 0; s < SR; ++s) rhs[s] = inR[s] ? rhs[s] : 0.0;
+            solve_H<C, DQP_R16N_NREF>(st, H, rdu, d, rhs, dwc, gdc, r);
+        }
+        double ds[SM], dz[SM];
+        am = INFINITY;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            const double dsc = inM[s] ? -gdc[s] : 0.0;
+            const double dzc = inM[s] ? -rsc[s] - d[s] * dsc : 0.0;
+            ds[s] = dsa[s] + dsc;
+            dz[s] = dza[s] + dzc;
+            am = fmin(am, fmin(ratio(z[s], dz[s], inM[s]), ratio(s_[s], ds[s], inM[s])));
+        }
+        alpha = fmin(0.999 * row_min(am), 1.0);
+        if (!done) {
+#pragma unroll
+            for (int s = 0; s < SR; ++s) w[s] = fma(alpha, dwa[s] + dwc[s], w[s]);
+#pragma unroll
+            for (int s = 0; s < SM; ++s) {
+                gw[s] = fma(alpha, gda[s] + gdc[s], gw[s]);
+                s_[s] = fma(alpha, ds[s], s_[s]);
+                z[s] = fma(alpha, dz[s], z[s]);
+            }
+            cc *= (1.0 - alpha);
+        }
+    }
+
+    // recover x = Lq^-T Qf [w* ; xy],  y = U^-T (c* delta w1 - xy - py - W^T z*)
+    double bw[SR], bs[SM], bz[SM];
+    vec_get<SR>(lds + C::oBw, bw, R, r);
+    vec_get<SM>(lds + C::oBs, bs, M, r);
+    vec_get<SM>(lds + C::oBz, bz, M, r);
+    double xh[SN];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) xh[s] = (s < SR && r + 16 * s < R) ? bw[s < SR ? s : 0] : 0.0;
+    double yv[SE];
+#pragma unroll
+    for (int s = 0; s < SE; ++s) yv[s] = 0.0;
+    if (E > 0) {
+        shift_up<C>(st.xy, xh, r);
+        apply_Qf<C>(lds, st.tau, xh, r);
+        double wz[SE];
+        mul_WT<C>(st, bz, wz, r);
+#pragma unroll
+        for (int s = 0; s < SE; ++s)
+            yv[s] = (r + 16 * s < E) ? bestc * delta * st.w1[s] - st.xy[s] - st.py[s] - wz[s] : 0.0;
+        solve_UT<C>(st, yv, r);
+    }
+    tri_solve_T<SN, N>(lds + C::oLq, st.rdq, xh, r);
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < SN; ++s)
+            if (r + 16 * s < N) P.zhat[qp * N + r + 16 * s] = xh[s];
+#pragma unroll
+        for (int s = 0; s < SM; ++s)
+            if (inM[s]) { P.lam[qp * M + r + 16 * s] = bz[s]; P.slack[qp * M + r + 16 * s] = bs[s]; }
+        if (E > 0) {
+#pragma unroll
+            for (int s = 0; s < SE; ++s)
+                if (r + 16 * s < E) P.nu[qp * E + r + 16 * s] = yv[s];
+        }
+        if (r == 0) {
+            if (P.info) { P.info[2 * qp] = st.status; P.info[2 * qp + 1] = iters; }
+            if (P.best_resid) P.best_resid[qp] = best;
+        }
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(64) void backward_kernel(KParams P)
+{
+    constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
+    constexpr int SN = C::SN, SM = C::SM, SE = C::SE, SR = C::SR;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
+    long long qp = (long long)blockIdx.x * 4 + qrow;
+    const bool live = qp < P.B;
+    if (!live) qp = P.B - 1;
+    double *lds = sm + qrow * C::ldsQPpad;
+
+    State<C> st;
+    setup<C, false>(P, qp, r, lds, st);
+
+    bool inN[SN], inM[SM], inE[SE], inR[SR];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) inN[s] = r + 16 * s < N;
+#pragma unroll
+    for (int s = 0; s < SM; ++s) inM[s] = r + 16 * s < M;
+#pragma unroll
+    for (int s = 0; s < SE; ++s) inE[s] = r + 16 * s < E;
+#pragma unroll
+    for (int s = 0; s < SR; ++s) inR[s] = r + 16 * s < R;
+
+    double zh[SN], g[SN], lam[SM], d[SM], nu[SE];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) {
+        zh[s] = inN[s] ? P.zin[qp * N + r + 16 * s] : 0.0;
+        g[s] = inN[s] ? P.gin[qp * N + r + 16 * s] : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < SM; ++s) {
+        lam[s] = inM[s] ? P.lamin[qp * M + r + 16 * s] : 0.0;
+        const double sl = inM[s] ? P.slackin[qp * M + r + 16 * s] : 1.0;
+        if (P.flags & DQP_FLAG_DENSE_BACKWARD) d[s] = inM[s] ? lam[s] / sl : 0.0;
+        else d[s] = inM[s] ? fmax(lam[s], 1e-8) / fmax(sl, 1e-8) : 0.0;        // qp.py:149
+    }
+#pragma unroll
+    for (int s = 0; s < SE; ++s) nu[s] = (E > 0 && inE[s]) ? P.nuin[qp * E + r + 16 * s] : 0.0;
+
+    double H[SR][R], rdu[SR];
+    factor_H<C>(st, d, H, rdu, r);
+    // g^ = Lq^-1 g ; [gw ; gy] = Qf^T g^
+    tri_solve<SN, N>(lds + C::oLq, st.rdq, g, r);
+    double gy[SE];
+#pragma unroll
+    for (int s = 0; s < SE; ++s) gy[s] = 0.0;
+    if (E > 0) {
+        apply_QfT<C>(lds, st.tau, g, r);
+        shift_down<C>(g, gy, r);
+    }
+    double dw[SR], gdw[SM], dlam[SM], dnu[SE];
+#pragma unroll
+    for (int s = 0; s < SR; ++s) dw[s] = inR[s] ? -g[s < SN ? s : 0] : 0.0;
+    lu_solve<SR, R>(H, rdu, dw, r);
+    mul_Gz<C>(st, dw, gdw);
+#pragma unroll
+    for (int s = 0; s < SM; ++s) dlam[s] = inM[s] ? d[s] * gdw[s] : 0.0;
+#pragma unroll
+    for (int s = 0; s < SE; ++s) dnu[s] = 0.0;
+    double dxh[SN];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) dxh[s] = (s < SR && r + 16 * s < R) ? dw[s < SR ? s : 0] : 0.0;
+    if (E > 0) {
+        double wz[SE];
+        mul_WT<C>(st, dlam, wz, r);
+#pragma unroll
+        for (int s = 0; s < SE; ++s) dnu[s] = inE[s] ? -(gy[s] + wz[s]) : 0.0;
+        solve_UT<C>(st, dnu, r);
+        apply_Qf<C>(lds, st.tau, dxh, r);
+    }
+    tri_solve_T<SN, N>(lds + C::oLq, st.rdq, dxh, r);
+
+    if (!live) return;
+#pragma unroll
+    for (int s = 0; s < SN; ++s)
+        if (P.dp && inN[s]) P.dp[qp * N + r + 16 * s] = dxh[s];
+#pragma unroll
+    for (int s = 0; s < SM; ++s)
+        if (P.dh && inM[s]) P.dh[qp * M + r + 16 * s] = -dlam[s];
+    if (E > 0) {
+#pragma unroll
+        for (int s = 0; s < SE; ++s)
+            if (P.db && inE[s]) P.db[qp * E + r + 16 * s] = -dnu[s];
+    }
+    if (P.dQ) {
+        double *o = P.dQ + qp * N * N;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double dxi = BC(dxh, i), zi = BC(zh, i);
+#pragma unroll
+            for (int s = 0; s < SN; ++s)
+                if (inN[s]) o[i * N + r + 16 * s] = 0.5 * (dxi * zh[s] + zi * dxh[s]);
+        }
+    }
+    if (P.dG) {
+        double *o = P.dG + qp * M * N;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const double dli = BC(dlam, i), li = BC(lam, i);
+#pragma unroll
+            for (int s = 0; s < SN; ++s)
+                if (inN[s]) o[i * N + r + 16 * s] = dli * zh[s] + li * dxh[s];
+        }
+    }
+    if (P.dA && E > 0) {
+        double *o = P.dA + qp * E * N;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const double dni = BC(dnu, i), ni = BC(nu, i);
+#pragma unroll
+            for (int s = 0; s < SN; ++s)
+                if (inN[s]) o[i * N + r + 16 * s] = dni * zh[s] + ni * dxh[s];
+        }
+    }
+    if (r == 0 && P.info) { P.info[2 * qp] = st.status; P.info[2 * qp + 1] = 0; }
+}
+
+template <class C, class K>
+int launch(K kernel, const KParams &P, void *stream)
+{
+    const size_t lds = (size_t)4 * C::ldsQPpad * sizeof(double);
+    if (lds > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return DQP_ERR_LAUNCH;
+    const int blocks = (P.B + 3) / 4;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+}  // namespace r16n
+
+#define DQP_R16N_SIZES(X) X(30, 30, 15) X(10, 5, 3) X(12, 8, 0)
+
+int r16n_forward(const KParams &P, void *stream)
+{
+#define X(n, m, e)                                                                       \
+    if (P.N == n && P.M == m && P.E == e)                                                \
+        return r16n::launch<r16n::Cfg<n, m, e>>(r16n::forward_kernel<r16n::Cfg<n, m, e>>, P, stream);
+    DQP_R16N_SIZES(X)
+#undef X
+    return 1;
+}
+
+int r16n_backward(const KParams &P, void *stream)
+{
+#define X(n, m, e)                                                                       \
+    if (P.N == n && P.M == m && P.E == e)                                                \
+        return r16n::launch<r16n::Cfg<n, m, e>>(r16n::backward_kernel<r16n::Cfg<n, m, e>>, P, stream);
+    DQP_R16N_SIZES(X)
+#undef X
+    return 1;
+}
+
+}  // namespace dqp

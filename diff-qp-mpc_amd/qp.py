@@ -30,6 +30,9 @@ Your problem may be infeasible or difficult.
 
 # per-problem early exit only once the best residual is below this (include/dqp.h)
 STALL_TOL = 1e-10
+# extra dqp_opts.flags OR-ed into every call (tests use DQP_FLAG_GENERIC_ONLY / _NO_NULLSPACE to
+# pin a kernel family; 0 = automatic dispatch)
+FORCE_FLAGS = 0
 
 
 class QPSolvers(Enum):
@@ -83,7 +86,7 @@ def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim):
     assert neq > 0 or nineq > 0                                   # qp.py:90
     dev = Q.device
     dims = _lib.dqp_dims(nBatch, nz, nineq, neq, sQ, sp, sG, sh, sA, sb)
-    opts = _lib.dqp_opts(eps, STALL_TOL, maxIter, notImprovedLim, 0, 0)
+    opts = _lib.dqp_opts(eps, STALL_TOL, maxIter, notImprovedLim, FORCE_FLAGS, 0)
     kw = dict(dtype=torch.float64, device=dev)
     zhat = torch.empty(nBatch, nz, **kw)
     lam = torch.empty(nBatch, nineq, **kw)
@@ -113,7 +116,7 @@ def _backward_impl(saved, zhat, lam, nu, slack, dl_dzhat, need, flags):
     dh = torch.empty(nBatch, nineq, **kw) if need[3] else None
     dA = torch.empty(nBatch, neq, nz, **kw) if (need[4] and neq > 0) else None
     db = torch.empty(nBatch, neq, **kw) if (need[5] and neq > 0) else None
-    opts = _lib.dqp_opts(0.0, 0.0, 0, 0, flags, 0)
+    opts = _lib.dqp_opts(0.0, 0.0, 0, 0, flags | FORCE_FLAGS, 0)
     with torch.cuda.device(dev):
         rc = lib.dqp_qp_backward(ctypes.byref(dims), ctypes.byref(opts), _ptr(Q), _ptr(G), _ptr(A),
                                  _ptr(zhat), _ptr(lam), _ptr(nu), _ptr(slack), _ptr(g),

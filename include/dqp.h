@@ -52,6 +52,8 @@ enum {
                                       without the 1e-8 clamps of QPFunction (qp.py:149)   */
 
 #define DQP_FLAG_GENERIC_ONLY 2u   /* testing: skip the size-specialised DPP-row kernels     */
+#define DQP_FLAG_REDUCED_HESSIAN 4u /* opt-in fast forward (null-space / reduced Hessian): zhat
+                                      accurate to ~1e-5 only; not the parity path            */
 
 typedef struct dqp_dims {
     int32_t nbatch;

@@ -29,6 +29,16 @@ DT = dict(rtol=1e-5, atol=1e-7)
 GT = dict(rtol=1e-4, atol=1e-6)
 
 
+@pytest.fixture(params=["auto", "generic"], autouse=True)
+def kernel_family(request):
+    """Every test runs against both kernel families: automatic dispatch (DPP-row kernels where
+    instantiated) and the generic one-QP-per-wavefront LDS kernels."""
+    from diff_qp_mpc_amd import qp as qpmod, _lib
+    qpmod.FORCE_FLAGS = {"auto": 0, "generic": _lib.DQP_FLAG_GENERIC_ONLY}[request.param]
+    yield request.param
+    qpmod.FORCE_FLAGS = 0
+
+
 @pytest.fixture(scope="module")
 def dqp():
     assert torch.cuda.is_available(), "these tests need a GPU"
@@ -171,6 +181,20 @@ def test_full_size_properties_and_oracle(dqp):
     og = oracle.qp_backward(Q, G, A, o["zhat"], o["lam"], o["nu"], o["slack"], ct.cpu().numpy())
     for k, t in zip("QpGhAb", g1):
         np.testing.assert_allclose(t.cpu().numpy()[cm], og["d" + k][cm], err_msg="d" + k, **GT)
+
+
+def test_reduced_hessian_fast_mode(dqp):
+    """Opt-in DQP_FLAG_REDUCED_HESSIAN forward: same optimum to the looser 1e-4 it promises."""
+    from diff_qp_mpc_amd import qp as qpmod, _lib
+    g = load("R_metric_b8")
+    ins = [dev(g["in_" + k], grad=False) for k in "QpGhAb"]
+    qpmod.FORCE_FLAGS = _lib.DQP_FLAG_REDUCED_HESSIAN
+    try:
+        zhat, lam, nu, slack, info, resid, _ = qpmod._forward_impl(*ins, 1e-12, 20, 3)
+    finally:
+        qpmod.FORCE_FLAGS = 0
+    np.testing.assert_allclose(zhat.cpu().numpy(), g["zhat"], rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(nu.cpu().numpy(), g["nu"], rtol=1e-3, atol=1e-3)
 
 
 def test_not_spd_raises(dqp):
