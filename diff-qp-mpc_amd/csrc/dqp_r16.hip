@@ -256,15 +256,18 @@ __device__ __forceinline__ void kkt_rhs(const State<C> &st, const double (&rxh)[
 }
 
 // x/y-part: dxh = -q + At^T (At q - ryt), dyt = -(At q - ryt), q = rxh + Gh^T wz
+// Also returns gtw = Gh^T wz and atd = At^T dyt, which the caller uses to keep Gh^T z and
+// At^T yt up to date without recomputing them every iteration.
 template <class C>
 __device__ __forceinline__ void kkt_xy(const State<C> &st, const double (&rxh)[C::SN],
                                        const double (&ryt)[C::SE], const double (&wz)[C::SM],
-                                       double (&dxh)[C::SN], double (&dyt)[C::SE], int r)
+                                       double (&dxh)[C::SN], double (&dyt)[C::SE],
+                                       double (&gtw)[C::SN], double (&atd)[C::SN], int r)
 {
     double q[C::SN];
-    mv_tr<C::SM, C::N, C::SN>(st.Gh, wz, q, r);
+    mv_tr<C::SM, C::N, C::SN>(st.Gh, wz, gtw, r);
 #pragma unroll
-    for (int s = 0; s < C::SN; ++s) { q[s] += rxh[s]; dxh[s] = -q[s]; }
+    for (int s = 0; s < C::SN; ++s) { q[s] = gtw[s] + rxh[s]; dxh[s] = -q[s]; atd[s] = 0.0; }
 #pragma unroll
     for (int s = 0; s < C::SE; ++s) dyt[s] = 0.0;
     if (C::E > 0) {
@@ -274,7 +277,7 @@ __device__ __forceinline__ void kkt_xy(const State<C> &st, const double (&rxh)[C
         for (int s = 0; s < C::SE; ++s) { e[s] -= ryt[s]; dyt[s] = -e[s]; }
         mv_tr<C::SE, C::N, C::SN>(st.Ah, e, at, r);
 #pragma unroll
-        for (int s = 0; s < C::SN; ++s) dxh[s] += at[s];
+        for (int s = 0; s < C::SN; ++s) { dxh[s] += at[s]; atd[s] = -at[s]; }
     }
 }
 
@@ -332,7 +335,8 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         factor_T<C>(lds, T, one, rdu, r);
         lu_solve<SM, M>(T, rdu, wz, r);
         __builtin_amdgcn_sched_barrier(0);
-        kkt_xy<C>(st, ph, mb, wz, xh, yt, r);
+        double gt0[SN], at0[SN];
+        kkt_xy<C>(st, ph, mb, wz, xh, yt, gt0, at0, r);
         double ms = INFINITY, mz = INFINITY;
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
@@ -350,6 +354,13 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     }
 
     STAMP(P, 6);
+    // gz = Gh^T z and ay = At^T yt are carried incrementally (updated with the step's own
+    // transposed products), so each iteration needs three transposed mat-vecs instead of five.
+    double gz[SN], ay[SN];
+    mv_tr<SM, N, SN>(st.Gh, z, gz, r);
+#pragma unroll
+    for (int s = 0; s < SN; ++s) ay[s] = 0.0;
+    if (E > 0) mv_tr<SE, N, SN>(st.Ah, yt, ay, r);
     double best = INFINITY;
     vec_put<SN>(lds + C::oBx, xh, N, r, dummy);
     vec_put<SM>(lds + C::oBs, s_, M, r, dummy);
@@ -361,16 +372,12 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     for (int it = 0; it < P.maxIter; ++it) {
         // residuals in hat coordinates                                    batch.py:93-108
         double rxh[SN], ryt[SE], rz[SM], tmpN[SN];
-        mv_tr<SM, N, SN>(st.Gh, z, rxh, r);
         vec_get<SN>(lds + C::oPh, tmpN, N, r);
 #pragma unroll
-        for (int s = 0; s < SN; ++s) rxh[s] += xh[s] + tmpN[s];
+        for (int s = 0; s < SN; ++s) rxh[s] = xh[s] + tmpN[s] + gz[s] + ay[s];
 #pragma unroll
         for (int s = 0; s < SE; ++s) ryt[s] = 0.0;
         if (E > 0) {
-            mv_tr<SE, N, SN>(st.Ah, yt, tmpN, r);
-#pragma unroll
-            for (int s = 0; s < SN; ++s) rxh[s] += tmpN[s];
             mv_nat<SE, N, SN>(st.Ah, xh, ryt, false);
             double btl[SE];
             vec_get<SE>(lds + C::oBt, btl, E, r);
@@ -466,14 +473,18 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         }
         __builtin_amdgcn_sched_barrier(0);
         // phase 3 (Gh/At live, T dead): x / y part of the combined direction
-        double dxh[SN], dyt[SE];
-        kkt_xy<C>(st, rxh, ryt, dz, dxh, dyt, r);
+        double dxh[SN], dyt[SE], gtd[SN], atd[SN];
+        kkt_xy<C>(st, rxh, ryt, dz, dxh, dyt, gtd, atd, r);
         alpha = fmin(0.999 * row_min(am), 1.0);
         if (it == 1) STAMP(P, 13);
         if (it == 0) STAMP(P, 8);
         if (!done) {
 #pragma unroll
-            for (int s = 0; s < SN; ++s) xh[s] = fma(alpha, dxh[s], xh[s]);
+            for (int s = 0; s < SN; ++s) {
+                xh[s] = fma(alpha, dxh[s], xh[s]);
+                gz[s] = fma(alpha, gtd[s], gz[s]);
+                ay[s] = fma(alpha, atd[s], ay[s]);
+            }
 #pragma unroll
             for (int s = 0; s < SM; ++s) { s_[s] = fma(alpha, ds[s], s_[s]); z[s] = fma(alpha, dz[s], z[s]); }
 #pragma unroll
@@ -565,7 +576,8 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P)
         lu_solve<SM, M>(T, rdu, dlam, r);
     }
     __builtin_amdgcn_sched_barrier(0);
-    kkt_xy<C>(st, g, zeroE, dlam, dxh, dyt, r);
+    double gtd[SN], atd[SN];
+    kkt_xy<C>(st, g, zeroE, dlam, dxh, dyt, gtd, atd, r);
     tri_solve_T<SN, N>(lds + C::oLq, st.rdq, dxh, r);                   // dx = Lq^-T dxh
     if (E > 0) tri_solve_T<SE, C::EC>(lds + C::oL1, st.rd1, dyt, r);    // dnu
 
