@@ -38,6 +38,22 @@ BWD_ELEMS = (NZ * NZ + NINEQ * NZ + NEQ * NZ + NZ + 2 * NINEQ + NEQ + NZ) + \
             (NZ * NZ + NZ + NINEQ * NZ + NINEQ + NEQ * NZ + NEQ)                             # 2385 + 2325
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # public MI355X spec (vector = matrix fp64); not in the guide
+# ~50 kFLOP per PDIPM iteration + 0.27 MFLOP one-time factorisations per QP
+FLOP_SETUP, FLOP_PER_ITER = 0.27e6, 50e3
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "v3_r16_pmc_summary.json")
+
+
+def measured_traffic(kernel_key):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+    (FETCH_SIZE and WRITE_SIZE collected in separate passes, in KB; gfx950 FETCH_SIZE counts
+    half of the fetched bytes, MI355X_MICROARCH.md §HBM -- confirmed here on the backward
+    kernel, whose 2 x FETCH_SIZE matches its algorithmic reads to 4 %).  None if no summary."""
+    try:
+        d = json.load(open(PMC_SUMMARY))
+        k = next(v for n, v in d.items() if kernel_key in n)
+        return (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+    except Exception:
+        return None
 
 
 def family_R(seed, B, nz, nineq, neq):
@@ -182,6 +198,7 @@ def main():
         fwd_bytes = FWD_ELEMS * 8 * B_PER_GPU
         bwd_bytes = BWD_ELEMS * 8 * B_PER_GPU
         fwd_gbs = fwd_bytes / (fwd_ms * 1e-3) / 1e9
+        fwd_flops = B_PER_GPU * (FLOP_SETUP + FLOP_PER_ITER * float(iters.mean()))
         out = {
             "metric": "QPs/sec (fwd+bwd), batch=4096 n=3 m=3 T=5",
             "value": qps, "unit": "QPs/sec", "n_gpus": world, "steps": args.steps,
@@ -192,12 +209,20 @@ def main():
                                    "BASELINE metric batch: B=4096/GPU nz=30 nineq=30 neq=15",
                        "global_batch": world * B_PER_GPU, "n_state": 3, "n_ctrl": 3, "T": 5,
                        "parallelism": "batch-shard x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "qp_forward_kernel",
+            "roofline": {"bound": "hbm", "kernel": "dqp::r16::forward_kernel<Cfg<30,30,15>>",
                          "achieved": fwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": fwd_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "avg_launch_ms": fwd_ms, "algorithmic_bytes_per_launch": fwd_bytes},
+                         "frac": fwd_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("forward"),
+                         "avg_launch_ms": fwd_ms, "algorithmic_bytes_per_launch": fwd_bytes,
+                         "note": "the path is fp64-issue bound, not HBM bound (DESIGN.md §4): "
+                                 "fp64 fraction below"},
+            "fp64": {"achieved_tflops": fwd_flops / (fwd_ms * 1e-3) / 1e12,
+                     "peak_tflops": FP64_PEAK_TFLOPS,
+                     "frac": fwd_flops / (fwd_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                     "flop_model": "SURVEY 8d: 0.27 MFLOP + 50 kFLOP x executed iterations per QP"},
             "kernels": {"qp_forward_kernel_ms": fwd_ms, "qp_backward_kernel_ms": bwd_ms,
                         "backward_GBps": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
+                        "backward_hbm_frac": bwd_bytes / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "backward_traffic": measured_traffic("backward"),
                         "pdipm_iters_mean": float(iters.mean()), "pdipm_iters_max": float(iters.max()),
                         "status_nonzero": status_bad},
         }
