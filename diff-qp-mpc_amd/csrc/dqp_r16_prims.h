@@ -68,7 +68,11 @@ __device__ __forceinline__ double frsqrt(double d)
 // Diagnostic phase stamps: compiled in only with -DDQP_STAMPS (tools/stamps.py builds that
 // variant itself).  Even a never-taken stamp branch perturbs register allocation of the
 // fully unrolled kernels by 2-3x, so the shipped build contains none.
-#ifndef DQP_STAMPS
+#if defined(DQP_MARKS)   /* asm comments at the phase boundaries, for reading the .s */
+#define DQP_STR2(x) #x
+#define DQP_STR(x) DQP_STR2(x)
+#define STAMP(P, i) asm volatile("; DQPMARK " DQP_STR(i))
+#elif !defined(DQP_STAMPS)
 #define STAMP(P, i) do { } while (0)
 #else
 #define STAMP(P, i)                                                                  \

@@ -183,6 +183,55 @@ def test_full_size_properties_and_oracle(dqp):
         np.testing.assert_allclose(t.cpu().numpy()[cm], og["d" + k][cm], err_msg="d" + k, **GT)
 
 
+@pytest.mark.parametrize("B", [1, 2, 3, 5, 4099])
+def test_ragged_batches_at_dpp_row_size(dqp, B):
+    """Batch sizes that are not a multiple of 4 QPs per wavefront (tail rows are masked)."""
+    Q, p, G, h, A, b = family_R(7, B, 30, 30, 15)
+    o = oracle.qp_forward(Q, p, G, h, A, b)
+    ins = [dev(a) for a in (Q, p, G, h, A, b)]
+    zhat = dqp.QPFunction(check_Q_spd=True, verbose=-1)(*ins)
+    cm = o["best_resid"] < 1e-8
+    np.testing.assert_allclose(zhat.detach().cpu().numpy()[cm], o["zhat"][cm], **ZT)
+    ct = np.random.default_rng(1).standard_normal((B, 30))
+    zhat.backward(dev(ct, grad=False))
+    og = oracle.qp_backward(Q, G, A, o["zhat"], o["lam"], o["nu"], o["slack"], ct)
+    # The gradient of a QP without strict complementarity (some lam_i ~ slack_i ~ 0) is not
+    # well defined: d = clamp(lam)/clamp(slack) (qp.py:149) swings by O(1) on 1e-10 changes of
+    # the forward iterate.  Compare where min_i max(lam_i, slack_i) is clearly positive.
+    cm &= np.maximum(o["lam"], o["slack"]).min(1) > 1e-5
+    assert cm.mean() > 0.95
+    for k, t in zip("QpGhAb", ins):
+        np.testing.assert_allclose(t.grad.cpu().numpy()[cm], og["d" + k][cm], err_msg="d" + k, **GT)
+    # and the backward kernel alone, fed the oracle's forward point, on ALL problems
+    from diff_qp_mpc_amd import qp as qpmod
+    dv = lambda a: dev(a, grad=False)
+    _, _, _, _, _, _, saved = qpmod._forward_impl(*[dv(a) for a in (Q, p, G, h, A, b)], 1e-12, 20, 3)
+    gr = qpmod._backward_impl(saved, dv(o["zhat"]), dv(o["lam"]), dv(o["nu"]), dv(o["slack"]), dv(ct),
+                              (True,) * 6, qpmod.FORCE_FLAGS)
+    for k, t in zip("QpGhAb", gr):
+        np.testing.assert_allclose(t.cpu().numpy(), og["d" + k], err_msg="bwd-only d" + k, **GT)
+
+
+def test_shared_parameters_at_dpp_row_size(dqp):
+    """Q, G, A without a batch dim (stride 0 in the C ABI) + .mean(0) gradients (qp.py:160-178)."""
+    B = 9
+    Q, p, G, h, A, b = family_R(11, B, 30, 30, 15)
+    Q0, G0, A0 = Q[0], G[0], A[0]
+    z0 = np.random.default_rng(2).standard_normal((B, 30))
+    h = z0 @ G0.T + np.random.default_rng(3).random((B, 30))
+    b = z0 @ A0.T
+    Qe, Ge, Ae = [oracle.expand(a, B, 3) for a in (Q0, G0, A0)]
+    o = oracle.qp_forward(Qe, p, Ge, h, Ae, b)
+    ins = [dev(a) for a in (Q0, p, G0, h, A0, b)]
+    zhat = dqp.QPFunction(check_Q_spd=False, verbose=-1)(*ins)
+    np.testing.assert_allclose(zhat.detach().cpu().numpy(), o["zhat"], **ZT)
+    zhat.backward(torch.ones_like(zhat))
+    og = oracle.qp_backward(Qe, Ge, Ae, o["zhat"], o["lam"], o["nu"], o["slack"], np.ones((B, 30)))
+    for k, t in zip("QpGhAb", ins):
+        want = og["d" + k].mean(0) if k in "QGA" else og["d" + k]
+        np.testing.assert_allclose(t.grad.cpu().numpy(), want, err_msg="d" + k, **GT)
+
+
 def test_reduced_hessian_fast_mode(dqp):
     """Opt-in DQP_FLAG_REDUCED_HESSIAN forward: same optimum to the looser 1e-4 it promises."""
     from diff_qp_mpc_amd import qp as qpmod, _lib
