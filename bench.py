@@ -146,11 +146,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    dev = torch.device("cuda", local_rank)
+    # DQP_BENCH_BACKEND=gloo + DQP_BENCH_ONE_DEVICE=1 rehearse the N>1 code path with several
+    # ranks on a single GPU (the 8-GPU run itself is the driver's job).
+    one_dev = os.environ.get("DQP_BENCH_ONE_DEVICE") == "1"
+    dev = torch.device("cuda", 0 if one_dev else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DQP_BENCH_BACKEND", "nccl")      # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     host_inputs = family_R(rank, B_PER_GPU, NZ, NINEQ, NEQ)
     hp = HotPath(dev, host_inputs)
@@ -158,9 +165,12 @@ def main():
 
     def step():
         hp.forward()
-        if world > 1:   # north_star: a single RCCL gather of the solved batch
-            dist.all_gather_into_tensor(gathered, hp.zhat)
+        work = None
+        if world > 1:   # north_star: a single RCCL gather of the solved batch, overlapped
+            work = dist.all_gather_into_tensor(gathered, hp.zhat, async_op=True)   # with backward
         hp.backward()
+        if work is not None:
+            work.wait()
 
     for _ in range(args.warmup):
         step()
@@ -176,9 +186,12 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         fev[k][0].record(); hp.forward(); fev[k][1].record()
+        work = None
         if world > 1:
-            dist.all_gather_into_tensor(gathered, hp.zhat)
+            work = dist.all_gather_into_tensor(gathered, hp.zhat, async_op=True)
         bev[k][0].record(); hp.backward(); bev[k][1].record()
+        if work is not None:
+            work.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
