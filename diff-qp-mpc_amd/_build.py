@@ -1,4 +1,9 @@
-"""Builds csrc/*.hip into csrc/libdqp_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+"""Builds csrc/*.hip into csrc/libdqp_hip.so for gfx950 (hipcc cross-compiles without a GPU).
+
+The DPP-row kernels keep whole matrices in VGPR arrays, so every loop over a register index is
+fully unrolled (far beyond clang's default pragma-unroll budget) and each size is its own
+translation unit; the objects are compiled in parallel.
+"""
 import os
 import shutil
 import subprocess
@@ -6,8 +11,24 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(CSRC, "libdqp_hip.so")
-SOURCES = ["dqp_pdipm.hip", "dqp_r16.hip", "dqp_r16n.hip", "dqp_mpc.hip"]
 ARCH = "gfx950"
+
+# (nz, nineq, neq) instantiations of the 4-QPs-per-wavefront kernels (csrc/dqp_r16.hip).
+# MPC shapes: nz = T(n+m), nineq = 2Tm, neq = Tn.
+R16_SIZES = [
+    (30, 30, 15),   # n=3 m=3 T=5: the BASELINE metric config
+    (20, 10, 15),   # n=3 m=1 T=5 (PendulumDx)
+    (15, 10, 10),   # n=2 m=1 T=5 (deqmpc pendulum)
+    (25, 10, 20),   # n=4 m=1 T=5 (cartpole-1)
+    (10, 5, 3), (12, 8, 0),   # small test sizes (with / without equalities)
+]
+# opt-in reduced-Hessian forward (csrc/dqp_r16n.hip, DQP_FLAG_REDUCED_HESSIAN)
+R16N_SIZES = [(30, 30, 15)]
+
+PLAIN_SOURCES = ["dqp_pdipm.hip", "dqp_mpc.hip"]
+SOURCES = PLAIN_SOURCES + ["dqp_r16.hip", "dqp_r16n.hip", "dqp_dispatch.hip"]
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+         "-mllvm", "-pragma-unroll-threshold=10000000", "-mllvm", "-unroll-threshold=10000000"]
 
 
 def hipcc():
@@ -17,36 +38,63 @@ def hipcc():
     raise RuntimeError("hipcc not found (set HIPCC=/path/to/hipcc)")
 
 
+def _deps():
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".hpp"))]
+    d.append(os.path.join(os.path.dirname(HERE), "include", "dqp.h"))
+    d.append(os.path.abspath(__file__))
+    return d
+
+
 def needs_build():
     if not os.path.exists(SO):
         return True
     t = os.path.getmtime(SO)
-    deps = [os.path.join(CSRC, s) for s in SOURCES]
-    deps.append(os.path.join(os.path.dirname(HERE), "include", "dqp.h"))
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return any(os.path.getmtime(d) > t for d in _deps() if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
+def _jobs():
+    """-> list of (object path, hipcc argv)"""
+    cc = hipcc()
+    jobs = []
+    variants = [("r16f", "dqp_r16.hip", R16_SIZES, []), ("r16b", "dqp_r16.hip", R16_SIZES, ["-DDQP_R16_BWD"]),
+                ("r16n", "dqp_r16n.hip", R16N_SIZES, [])]
+    for tag, src, sizes, extra in variants:
+        for n, m, e in sorted(sizes, key=lambda t: -t[0] * t[1]):        # longest compiles first
+            obj = os.path.join(CSRC, "dqp_%s_%d_%d_%d.o" % (tag, n, m, e))
+            jobs.append((obj, [cc] + FLAGS + extra + ["-DDQP_R16_N=%d" % n, "-DDQP_R16_M=%d" % m,
+                                                      "-DDQP_R16_E=%d" % e, "-c",
+                                                      os.path.join(CSRC, src), "-o", obj]))
+    for src in PLAIN_SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        jobs.append((obj, [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]))
+    jobs.sort(key=lambda j: 0 if ("_30_30_15" in j[0] or "pdipm" in j[0]) else 1)
+    lst = lambda sizes: " ".join("X(%d,%d,%d)" % s for s in sizes)
+    obj = os.path.join(CSRC, "dqp_dispatch.o")
+    jobs.append((obj, [cc] + FLAGS + ["-DDQP_R16_SIZE_LIST=" + lst(R16_SIZES),
+                                      "-DDQP_R16N_SIZE_LIST=" + lst(R16N_SIZES),
+                                      "-c", os.path.join(CSRC, "dqp_dispatch.hip"), "-o", obj]))
+    return jobs
+
+
+def build(force=False, verbose=False, max_parallel=None):
     if not force and not needs_build():
         return SO
-    # The DPP-row kernels keep whole matrices in VGPR arrays: every loop over a register index
-    # must be fully unrolled, far beyond clang's default pragma-unroll budget.
-    flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-             "-mllvm", "-pragma-unroll-threshold=10000000", "-mllvm", "-unroll-threshold=10000000"]
-    objs = []
-    procs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc()] + flags + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((subprocess.Popen(cmd), cmd))
-        objs.append(obj)
-    for pr, cmd in procs:
+    jobs = _jobs()
+    max_parallel = max_parallel or max(1, min(len(jobs), (os.cpu_count() or 2)))
+    pending, running = list(jobs), []
+    while pending or running:
+        while pending and len(running) < max_parallel:
+            obj, cmd = pending.pop(0)
+            if verbose:
+                print(" ".join(cmd))
+            running.append((subprocess.Popen(cmd), cmd))
+        pr, cmd = running.pop(0)
         if pr.wait() != 0:
+            for other, _ in running:
+                other.kill()
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] + objs)
+    subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] +
+                          [obj for obj, _ in jobs])
     return SO
 
 

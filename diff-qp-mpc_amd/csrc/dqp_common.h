@@ -36,7 +36,6 @@ int r16_forward(const KParams &P, void *stream);
 int r16_backward(const KParams &P, void *stream);
 // null-space / reduced-Hessian DPP-row kernels (dqp_r16n.hip); same return convention
 int r16n_forward(const KParams &P, void *stream);
-int r16n_backward(const KParams &P, void *stream);
 
 }  // namespace dqp
 #endif

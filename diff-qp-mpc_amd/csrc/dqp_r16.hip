@@ -644,26 +644,29 @@ int launch(K kernel, const KParams &P, void *stream)
 
 }  // namespace r16
 
-#define DQP_R16_SIZES(X) X(30, 30, 15) X(10, 5, 3) X(12, 8, 0)
+// One translation unit per size: _build.py compiles this file once for every entry of
+// R16_SIZES with -DDQP_R16_N/M/E (in parallel) and dqp_dispatch.hip routes to the matching
+// dqp::r16_forward_<N>_<M>_<E>.
+#if !defined(DQP_R16_N) || !defined(DQP_R16_M) || !defined(DQP_R16_E)
+#error "compile with -DDQP_R16_N=.. -DDQP_R16_M=.. -DDQP_R16_E=.."
+#endif
+#define DQP_CAT2(a, n, m, e) a##n##_##m##_##e
+#define DQP_CAT(a, n, m, e) DQP_CAT2(a, n, m, e)
 
-int r16_forward(const KParams &P, void *stream)
+// -DDQP_R16_BWD selects the backward kernel: forward and backward of one size are separate
+// objects so that the two long compiles run side by side.
+#ifndef DQP_R16_BWD
+int DQP_CAT(r16_forward_, DQP_R16_N, DQP_R16_M, DQP_R16_E)(const KParams &P, void *stream)
 {
-#define X(n, m, e)                                                                     \
-    if (P.N == n && P.M == m && P.E == e)                                              \
-        return r16::launch<r16::Cfg<n, m, e>>(r16::forward_kernel<r16::Cfg<n, m, e>>, P, stream);
-    DQP_R16_SIZES(X)
-#undef X
-    return 1;
+    using C = r16::Cfg<DQP_R16_N, DQP_R16_M, DQP_R16_E>;
+    return r16::launch<C>(r16::forward_kernel<C>, P, stream);
 }
-
-int r16_backward(const KParams &P, void *stream)
+#else
+int DQP_CAT(r16_backward_, DQP_R16_N, DQP_R16_M, DQP_R16_E)(const KParams &P, void *stream)
 {
-#define X(n, m, e)                                                                     \
-    if (P.N == n && P.M == m && P.E == e)                                              \
-        return r16::launch<r16::Cfg<n, m, e>>(r16::backward_kernel<r16::Cfg<n, m, e>>, P, stream);
-    DQP_R16_SIZES(X)
-#undef X
-    return 1;
+    using C = r16::Cfg<DQP_R16_N, DQP_R16_M, DQP_R16_E>;
+    return r16::launch<C>(r16::backward_kernel<C>, P, stream);
 }
+#endif
 
 }  // namespace dqp

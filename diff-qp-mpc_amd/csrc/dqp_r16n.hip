@@ -726,125 +726,6 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     }
 }
 
-template <class C>
-__global__ __launch_bounds__(64) void backward_kernel(KParams P)
-{
-    constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
-    constexpr int SN = C::SN, SM = C::SM, SE = C::SE, SR = C::SR;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
-    long long qp = (long long)blockIdx.x * 4 + qrow;
-    const bool live = qp < P.B;
-    if (!live) qp = P.B - 1;
-    double *lds = sm + qrow * C::ldsQPpad;
-
-    State<C> st;
-    setup<C, false>(P, qp, r, lds, st);
-
-    bool inN[SN], inM[SM], inE[SE], inR[SR];
-#pragma unroll
-    for (int s = 0; s < SN; ++s) inN[s] = r + 16 * s < N;
-#pragma unroll
-    for (int s = 0; s < SM; ++s) inM[s] = r + 16 * s < M;
-#pragma unroll
-    for (int s = 0; s < SE; ++s) inE[s] = r + 16 * s < E;
-#pragma unroll
-    for (int s = 0; s < SR; ++s) inR[s] = r + 16 * s < R;
-
-    double zh[SN], g[SN], lam[SM], d[SM], nu[SE];
-#pragma unroll
-    for (int s = 0; s < SN; ++s) {
-        zh[s] = inN[s] ? P.zin[qp * N + r + 16 * s] : 0.0;
-        g[s] = inN[s] ? P.gin[qp * N + r + 16 * s] : 0.0;
-    }
-#pragma unroll
-    for (int s = 0; s < SM; ++s) {
-        lam[s] = inM[s] ? P.lamin[qp * M + r + 16 * s] : 0.0;
-        const double sl = inM[s] ? P.slackin[qp * M + r + 16 * s] : 1.0;
-        if (P.flags & DQP_FLAG_DENSE_BACKWARD) d[s] = inM[s] ? lam[s] / sl : 0.0;
-        else d[s] = inM[s] ? fmax(lam[s], 1e-8) / fmax(sl, 1e-8) : 0.0;        // qp.py:149
-    }
-#pragma unroll
-    for (int s = 0; s < SE; ++s) nu[s] = (E > 0 && inE[s]) ? P.nuin[qp * E + r + 16 * s] : 0.0;
-
-    double H[SR][R], rdu[SR];
-    factor_H<C>(st, d, H, rdu, r);
-    // g^ = Lq^-1 g ; [gw ; gy] = Qf^T g^
-    tri_solve<SN, N>(lds + C::oLq, st.rdq, g, r);
-    double gy[SE];
-#pragma unroll
-    for (int s = 0; s < SE; ++s) gy[s] = 0.0;
-    if (E > 0) {
-        apply_QfT<C>(lds, st.tau, g, r);
-        shift_down<C>(g, gy, r);
-    }
-    double dw[SR], gdw[SM], dlam[SM], dnu[SE];
-#pragma unroll
-    for (int s = 0; s < SR; ++s) dw[s] = inR[s] ? -g[s < SN ? s : 0] : 0.0;
-    lu_solve<SR, R>(H, rdu, dw, r);
-    mul_Gz<C>(st, dw, gdw);
-#pragma unroll
-    for (int s = 0; s < SM; ++s) dlam[s] = inM[s] ? d[s] * gdw[s] : 0.0;
-#pragma unroll
-    for (int s = 0; s < SE; ++s) dnu[s] = 0.0;
-    double dxh[SN];
-#pragma unroll
-    for (int s = 0; s < SN; ++s) dxh[s] = (s < SR && r + 16 * s < R) ? dw[s < SR ? s : 0] : 0.0;
-    if (E > 0) {
-        double wz[SE];
-        mul_WT<C>(st, dlam, wz, r);
-#pragma unroll
-        for (int s = 0; s < SE; ++s) dnu[s] = inE[s] ? -(gy[s] + wz[s]) : 0.0;
-        solve_UT<C>(st, dnu, r);
-        apply_Qf<C>(lds, st.tau, dxh, r);
-    }
-    tri_solve_T<SN, N>(lds + C::oLq, st.rdq, dxh, r);
-
-    if (!live) return;
-#pragma unroll
-    for (int s = 0; s < SN; ++s)
-        if (P.dp && inN[s]) P.dp[qp * N + r + 16 * s] = dxh[s];
-#pragma unroll
-    for (int s = 0; s < SM; ++s)
-        if (P.dh && inM[s]) P.dh[qp * M + r + 16 * s] = -dlam[s];
-    if (E > 0) {
-#pragma unroll
-        for (int s = 0; s < SE; ++s)
-            if (P.db && inE[s]) P.db[qp * E + r + 16 * s] = -dnu[s];
-    }
-    if (P.dQ) {
-        double *o = P.dQ + qp * N * N;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const double dxi = BC(dxh, i), zi = BC(zh, i);
-#pragma unroll
-            for (int s = 0; s < SN; ++s)
-                if (inN[s]) o[i * N + r + 16 * s] = 0.5 * (dxi * zh[s] + zi * dxh[s]);
-        }
-    }
-    if (P.dG) {
-        double *o = P.dG + qp * M * N;
-#pragma unroll
-        for (int i = 0; i < M; ++i) {
-            const double dli = BC(dlam, i), li = BC(lam, i);
-#pragma unroll
-            for (int s = 0; s < SN; ++s)
-                if (inN[s]) o[i * N + r + 16 * s] = dli * zh[s] + li * dxh[s];
-        }
-    }
-    if (P.dA && E > 0) {
-        double *o = P.dA + qp * E * N;
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-            const double dni = BC(dnu, i), ni = BC(nu, i);
-#pragma unroll
-            for (int s = 0; s < SN; ++s)
-                if (inN[s]) o[i * N + r + 16 * s] = dni * zh[s] + ni * dxh[s];
-        }
-    }
-    if (r == 0 && P.info) { P.info[2 * qp] = st.status; P.info[2 * qp + 1] = 0; }
-}
-
 template <class C, class K>
 int launch(K kernel, const KParams &P, void *stream)
 {
@@ -860,26 +741,16 @@ int launch(K kernel, const KParams &P, void *stream)
 
 }  // namespace r16n
 
-#define DQP_R16N_SIZES(X) X(30, 30, 15) X(10, 5, 3) X(12, 8, 0)
+#if !defined(DQP_R16_N) || !defined(DQP_R16_M) || !defined(DQP_R16_E)
+#error "compile with -DDQP_R16_N=.. -DDQP_R16_M=.. -DDQP_R16_E=.."
+#endif
+#define DQP_CAT2(a, n, m, e) a##n##_##m##_##e
+#define DQP_CAT(a, n, m, e) DQP_CAT2(a, n, m, e)
 
-int r16n_forward(const KParams &P, void *stream)
+int DQP_CAT(r16n_forward_, DQP_R16_N, DQP_R16_M, DQP_R16_E)(const KParams &P, void *stream)
 {
-#define X(n, m, e)                                                                       \
-    if (P.N == n && P.M == m && P.E == e)                                                \
-        return r16n::launch<r16n::Cfg<n, m, e>>(r16n::forward_kernel<r16n::Cfg<n, m, e>>, P, stream);
-    DQP_R16N_SIZES(X)
-#undef X
-    return 1;
-}
-
-int r16n_backward(const KParams &P, void *stream)
-{
-#define X(n, m, e)                                                                       \
-    if (P.N == n && P.M == m && P.E == e)                                                \
-        return r16n::launch<r16n::Cfg<n, m, e>>(r16n::backward_kernel<r16n::Cfg<n, m, e>>, P, stream);
-    DQP_R16N_SIZES(X)
-#undef X
-    return 1;
+    using C = r16n::Cfg<DQP_R16_N, DQP_R16_M, DQP_R16_E>;
+    return r16n::launch<C>(r16n::forward_kernel<C>, P, stream);
 }
 
 }  // namespace dqp

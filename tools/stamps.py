@@ -10,10 +10,12 @@ from diff_qp_mpc_amd import _lib, _build
 # build the instrumented variant next to the product library (never loaded by the product)
 so = os.path.join(_build.CSRC, "libdqp_hip_stamps.so")
 if not os.path.exists(so):
-    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-                           "-DDQP_STAMPS", "-mllvm", "-pragma-unroll-threshold=10000000", "-mllvm",
-                           "-unroll-threshold=10000000", "-o", so] +
-                          [os.path.join(_build.CSRC, f) for f in _build.SOURCES])
+    objs = []
+    for obj, cmd in _build._jobs():
+        o2 = obj.replace(".o", ".stamps.o")
+        subprocess.check_call([c if c != obj else o2 for c in cmd] + ["-DDQP_STAMPS"])
+        objs.append(o2)
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", so] + objs)
 _build.SO = so
 lib = _lib.load()
 lib.dqp_debug_set_stamps.argtypes = [ctypes.c_void_p]
