@@ -1,0 +1,171 @@
+"""AL_mpc.MPC with the reference's interface (qpth/AL_mpc.py:116-439): augmented-Lagrangian MPC,
+`al_iter` outer multiplier/penalty updates around `al_utils.NewtonAL`.
+
+    ctrl = MPC(n_state, n_ctrl, T, u_lower=..., u_upper=..., n_batch=B, u_init=..., dtype=torch.float64)
+    ctrl.reinitialize(x0, mask)                       # required before the first forward (AL_mpc.py:432)
+    x, u = ctrl(x0, QuadCost(C, c), dx, dx_jac)       # batch-major: C (B,T,nt,nt) c (B,T,nt)
+                                                      # returns x (B,T,n), u (B,T,m) in float32
+
+State carried across calls, as in the reference (AL_mpc.py:193-195,250-251,314-318): `lamda_prev`,
+`rho_prev`, `cost_lam_hist` (the warm start looks up the stored AL iterate whose cost was already
+below the new starting cost), `x_init`, `u_init`, `just_initialized`.
+"""
+import torch
+from torch.nn import Module
+
+from . import al_utils
+from .al_utils import QuadCost, LinDx  # noqa: F401  (re-exported like the reference module)
+
+
+def _detach(t):
+    if t is None or not torch.is_tensor(t):
+        return t
+    return t.detach() if t.requires_grad else t
+
+
+class MPC(Module):
+    def __init__(self, n_state, n_ctrl, T, u_lower=None, u_upper=None, u_init=None, x_init=None,
+                 al_iter=2, verbose=0, eps=1e-7, back_eps=1e-7, n_batch=None, linesearch_decay=0.2,
+                 max_linesearch_iter=10, exit_unconverged=True, detach_unconverged=True,
+                 backprop=True, slew_rate_penalty=None, solver_type='dense',
+                 add_goal_constraint=False, x_goal=None, diag_cost=True, ineqG=None, ineqh=None,
+                 dtype=torch.float64):
+        super().__init__()
+        assert (u_lower is None) == (u_upper is None)
+        assert max_linesearch_iter > 0
+        if u_lower is None:
+            raise NotImplementedError("the reference's AL_mpc.MPC requires control bounds (AL_mpc.py:149-150)")
+        if add_goal_constraint or ineqG is not None or not diag_cost:
+            raise NotImplementedError("goal / general inequality constraints and dense costs are not "
+                                      "reachable in the reference's al_solve either")
+        self.dtype = dtype
+        self.n_state, self.n_ctrl, self.T = n_state, n_ctrl, T
+        self.u_lower = _detach(u_lower.to(dtype))
+        self.u_upper = _detach(u_upper.to(dtype))
+        self.x_lower = self.x_upper = None
+        self.x_goal, self.ineqG, self.ineqh = x_goal, ineqG, ineqh
+        self.u_init, self.x_init = _detach(u_init), _detach(x_init)
+        self.verbose, self.eps, self.back_eps, self.n_batch = verbose, eps, back_eps, n_batch
+        self.linesearch_decay, self.max_linesearch_iter = linesearch_decay, max_linesearch_iter
+        self.exit_unconverged, self.detach_unconverged = exit_unconverged, detach_unconverged
+        self.backprop, self.slew_rate_penalty, self.solver_type = backprop, slew_rate_penalty, solver_type
+        self.add_goal_constraint, self.diag_cost, self.al_iter = add_goal_constraint, diag_cost, al_iter
+        self.neq = n_state * T
+        self.nineq = 2 * n_ctrl * T
+        self.dyn_res_crit, self.dyn_res_factor = 1e-4, 10
+        self.rho_prev = 1.0
+        self.lamda_prev = torch.zeros(n_batch, self.neq + self.nineq).to(self.u_upper)
+        self.dyn_res_prev = 1000000
+        self.mask = torch.ones(n_batch, T, 1).to(self.u_upper)
+
+    # ------------------------------------------------------------------ AL_mpc.py:198-252
+    def forward(self, x0, cost, dx, dx_jac, u_init=None, x_init=None):
+        B = self.n_batch if self.n_batch is not None else cost.C.size(0)
+        assert cost.C.ndimension() == 4
+        assert x0.ndimension() == 2 and x0.size(0) == B
+
+        def batched(t):
+            return t.unsqueeze(0).expand(B, self.T, -1).clone() if t.ndimension() == 2 else t
+
+        if u_init is not None:
+            u = batched(u_init)
+        elif self.u_init is None:
+            u = torch.zeros(B, self.T, self.n_ctrl).type_as(x0.data)
+        else:
+            u = batched(self.u_init)
+        u = u.type_as(x0.data)
+        if x_init is not None:
+            x = batched(x_init)
+        elif self.x_init is None:
+            x = self.rollout(x0, u, dx)
+        else:
+            x = batched(self.x_init)
+        x = x.type_as(x0.data)
+        if self.diag_cost:
+            cost = QuadCost(cost.C.diagonal(dim1=-2, dim2=-1), cost.c)
+        x, u = self.al_solve(x, u, dx, dx_jac, x0, cost)
+        self.x_init, self.u_init = x, u
+        return (x, u)
+
+    # ------------------------------------------------------------------ AL_mpc.py:254-321
+    def al_solve(self, x, u, dx, dx_jac, x0, cost, lamda_init=None, rho_init=None):
+        dt = self.dtype
+        x, u, x0 = x.to(dt), u.to(dt), x0.to(dt)
+        lamda = self.lamda_prev.to(dt) if lamda_init is None else lamda_init
+        rho = self.rho_prev if rho_init is None else rho_init
+        with torch.no_grad():
+            xu0 = torch.cat((x, u), dim=2)
+            cost_start = self.compute_cost(xu0, cost.C.double(), cost.c.double())
+            if not self.just_initialized:
+                hist = [torch.stack(h[::-1], dim=0) for h in self.cost_lam_hist]
+                lamda, rho = al_utils.warm_start_al(x, lamda, rho, cost_start, *hist)
+        Q, q = cost.C.to(dt), cost.c.to(dt)
+        history = [[cost_start], [lamda], [rho]]
+        for _ in range(self.al_iter):
+            xu = torch.cat((x, u), dim=2).detach().clone()
+            rho_i = rho
+            out, status = al_utils.NewtonAL.apply(
+                lambda xi, Qi, qi, yi, x0i=x0, rhoi=rho_i, grad=False:
+                    self.merit_function(xi, Qi, qi, dx, x0i, yi, rhoi, grad),
+                lambda xi: self.dyn_res(xi, dx, x0),
+                lambda xi, Qi, qi: self.compute_cost(xi, Qi, qi),
+                lambda xi, Qi, qi, yi: self.merit_grad_hess(xi, Qi, qi, dx, dx_jac, x0, yi, rho_i),
+                xu, x0, lamda, rho, Q, q, 1e-3, 1e-6, True)
+            x, u = out[:, :, :self.n_state], out[:, :, self.n_state:]
+            with torch.no_grad():
+                res, res_clamp = self.dyn_res(torch.cat((x, u), dim=2), dx, x0, res_type='both')
+                lamda = lamda + rho * res                                 # AL_mpc.py:299
+                lamda = torch.cat([lamda[:, :self.neq], lamda[:, self.neq:].clamp(min=0)], dim=1)
+                cost_res = self.compute_cost(out, Q, q)
+                dyn_res_clamp = res_clamp.view(self.n_batch, -1).norm(dim=-1)
+                rho = rho * 10                                             # AL_mpc.py:307
+                history[0].append(cost_res)
+                history[1].append(lamda)
+                history[2].append(rho)
+        self.cost_lam_hist = history
+        self.lamda_prev, self.rho_prev, self.dyn_res_prev = lamda, rho, dyn_res_clamp
+        self.just_initialized = False
+        return x.float(), u.float()                                        # AL_mpc.py:319-320
+
+    # ------------------------------------------------------------------ thin wrappers (AL_mpc.py:323-429)
+    def merit_function(self, xu, Q, q, dx, x0, lamda, rho, grad=False):
+        return al_utils.merit_function(xu, Q, q, dx, x0, lamda, rho, self.x_lower, self.x_upper,
+                                       self.u_lower, self.u_upper, self.diag_cost)
+
+    def merit_grad_hess(self, xu, Q, q, dx, dx_jac, x0, lamda, rho):
+        return al_utils.merit_grad_hessian(xu, Q, q, dx, dx_jac, x0, lamda, rho, self.x_lower,
+                                           self.x_upper, self.u_lower, self.u_upper, self.diag_cost)
+
+    def dyn_res(self, xu, dx, x0, res_type='clamp'):
+        res, res_clamp = al_utils.dyn_res(xu, dx, x0, self.x_lower, self.x_upper, self.u_lower, self.u_upper)
+        if res_type == 'noclamp':
+            return res
+        if res_type == 'clamp':
+            return res_clamp
+        return res, res_clamp
+
+    def rollout(self, x, actions, dynamics):
+        xs = [x]
+        for t in range(self.T - 1):
+            xt, ut = xs[t], actions[:, t]
+            if isinstance(dynamics, LinDx):
+                nxt = torch.bmm(dynamics.F[:, t], torch.cat([xt, ut], dim=-1).unsqueeze(2)).squeeze(2) \
+                    + dynamics.f[:, t]
+            else:
+                nxt = dynamics(xt, ut)
+            xs.append(nxt)
+        return torch.stack(xs, 1)
+
+    def compute_cost(self, xu, Q, q):
+        return al_utils.compute_cost(xu, Q, q, self.diag_cost)
+
+    def compute_cost_gradient(self, xu, Q, q):
+        return al_utils.compute_cost_gradient(xu, Q, q, self.diag_cost)
+
+    def reinitialize(self, x, mask):
+        self.u_init = self.x_init = None
+        self.rho_prev = torch.ones((self.n_batch, 1), device=x.device, dtype=x.dtype)
+        self.lamda_prev = torch.zeros(self.n_batch, self.neq + self.nineq, device=x.device, dtype=x.dtype)
+        self.dyn_res_prev = 1000000
+        self.just_initialized = True
+        self.mask = mask

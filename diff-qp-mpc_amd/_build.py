@@ -25,7 +25,7 @@ R16_SIZES = [
 # opt-in reduced-Hessian forward (csrc/dqp_r16n.hip, DQP_FLAG_REDUCED_HESSIAN)
 R16N_SIZES = [(30, 30, 15)]
 
-PLAIN_SOURCES = ["dqp_pdipm.hip", "dqp_mpc.hip"]
+PLAIN_SOURCES = ["dqp_pdipm.hip", "dqp_mpc.hip", "dqp_al.hip"]
 SOURCES = PLAIN_SOURCES + ["dqp_r16.hip", "dqp_r16n.hip", "dqp_dispatch.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-mllvm", "-pragma-unroll-threshold=10000000", "-mllvm", "-unroll-threshold=10000000"]

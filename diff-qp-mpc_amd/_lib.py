@@ -36,7 +36,13 @@ DQP_MAX_DIM = 64
 
 # every symbol include/dqp.h declares
 SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes",
-           "dqp_qp_forward", "dqp_qp_backward", "dqp_mpc_assemble", "dqp_mpc_assemble_backward")
+           "dqp_qp_forward", "dqp_qp_backward", "dqp_mpc_assemble", "dqp_mpc_assemble_backward",
+           "dqp_al_newton_step", "dqp_al_chol_solve")
+
+
+class dqp_al_dims(ctypes.Structure):
+    _fields_ = [("nbatch", ctypes.c_int32), ("nz", ctypes.c_int32), ("ncon", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class dqp_mpc_dims(ctypes.Structure):
@@ -77,6 +83,10 @@ def load():
     lib.dqp_mpc_assemble.argtypes = [ctypes.POINTER(dqp_mpc_dims)] + [_dp] * 14
     lib.dqp_mpc_assemble_backward.restype = ctypes.c_int
     lib.dqp_mpc_assemble_backward.argtypes = [ctypes.POINTER(dqp_mpc_dims)] + [_dp] * 10
+    lib.dqp_al_newton_step.restype = ctypes.c_int
+    lib.dqp_al_newton_step.argtypes = [ctypes.POINTER(dqp_al_dims)] + [_dp] * 8
+    lib.dqp_al_chol_solve.restype = ctypes.c_int
+    lib.dqp_al_chol_solve.argtypes = [ctypes.POINTER(dqp_al_dims)] + [_dp] * 4
     _lib = lib
     return lib
 

@@ -1,0 +1,285 @@
+"""Augmented-Lagrangian Newton solver, mirror of qpth/al_utils.py.
+
+Public names follow the reference so call sites read the same:
+    QuadCost, LinDx                      al_utils.py:8-13
+    NewtonAL.apply(meritfn, dyn_fn, cost_fn, merit_grad_hessfn, xi, x0, lam, rho, Q, q,
+                   threshold, eps, ls) -> (x_est, status)           al_utils.py:363-500
+    merit_function, merit_grad_hessian, dyn_res, compute_cost, compute_cost_gradient,
+    line_search_newton, warm_start_al                               al_utils.py:16-360,503-527
+
+What runs where.  The Hessian assembly diag(Q) + rho Jc^T Jc, its Cholesky factorisation and the
+Newton solve (al_utils.py:96-102,414-418) and the backward solve (al_utils.py:477-480) are the
+HIP kernels of csrc/dqp_al.hip behind dqp_al_newton_step / dqp_al_chol_solve.  Residuals,
+Jacobian blocks, the merit function and the 20-way line search call the user's Python dynamics
+(`dx`, `dx_jac`), exactly as the reference does, and are device-tensor torch ops.
+
+Differences from the reference: `merit_grad_hessian` returns (grad, HessianTerms) -- the pieces
+the kernel consumes (clamped Jacobian, cost diagonal, rho) -- instead of a materialised
+(B,nz,nz) Hessian; `HessianTerms.dense()` builds it when the rare LU fallback needs it.
+Only diagonal costs (`diag_cost=True`, the only mode AL_mpc.MPC.forward reaches, AL_mpc.py:247-248)
+are supported.
+"""
+import ctypes
+from collections import namedtuple
+
+import torch
+
+from . import _lib
+
+QuadCost = namedtuple("QuadCost", "C c")
+LinDx = namedtuple("LinDx", "F f")
+QuadCost.__new__.__defaults__ = (None,) * len(QuadCost._fields)
+LinDx.__new__.__defaults__ = (None,) * len(LinDx._fields)
+
+N_LINESEARCH = 20          # al_utils.py:504
+MAX_NEWTON_STEPS = 4       # al_utils.py:391
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(dev):
+    return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("diff_qp_mpc_amd AL solver runs only on a GPU (HIP); there is no CPU fallback.")
+
+
+# ------------------------------------------------------------------------------------------
+# residuals and Jacobians of  x_{t+1} = f(x_t, u_t), x_0 = x0, u_lower <= u <= u_upper
+# ------------------------------------------------------------------------------------------
+def _split(xu, n_state):
+    return xu[..., :n_state], xu[..., n_state:]
+
+
+def _step(dx, x, u):
+    """x_next for the first T-1 knots; dx is a callable or a LinDx (AL_mpc.py:336-339)."""
+    B, T, n = x.shape
+    m = u.shape[-1]
+    if isinstance(dx, LinDx):
+        xu = torch.cat((x, u), dim=2)[:, :-1]
+        return (dx.F.permute(1, 0, 2, 3) * xu[:, :, None, :]).sum(-1) + dx.f.permute(1, 0, 2)
+    return dx(x[:, :-1].reshape(-1, n), u[:, :-1].reshape(-1, m)).view(B, T - 1, n)
+
+
+def dyn_res_eq(x, u, dx, x0):
+    """[x_{t+1} - f(x_t,u_t)]_{t<T-1} then x_0 - x0   (al_utils.py:188-205)."""
+    B = x.shape[0]
+    gap = x[:, 1:] - _step(dx, x, u)
+    return torch.cat((gap, (x[:, :1] - x0[:, None])), dim=1).reshape(B, -1)
+
+
+def dyn_res_ineq(x, u, x0, x_lower, x_upper, u_lower, u_upper):
+    """per knot [u - u_upper, u_lower - u]; clamp at 0 for the penalty term (al_utils.py:266-291)."""
+    B = x.shape[0]
+    res = torch.cat((u - u_upper, u_lower - u), dim=2).reshape(B, -1)
+    return res, res.clamp(min=0)
+
+
+def dyn_res(xu, dx, x0, x_lower=None, x_upper=None, u_lower=None, u_upper=None):
+    """al_utils.py:321-336 -> (res, res_clamp), each (B, neq + nineq)."""
+    x, u = _split(xu, x0.shape[-1])
+    eq = dyn_res_eq(x, u, dx, x0)
+    iq, iqc = dyn_res_ineq(x, u, x0, x_lower, x_upper, u_lower, u_upper)
+    return torch.cat((eq, iq), 1), torch.cat((eq, iqc), 1)
+
+
+def constraint_jacobian(xu, x0, dx_jac, u_lower, u_upper):
+    """Residuals and the dense constraint Jacobian (al_utils.py:162-186,212-318).
+
+    Returns res, res_clamp (B,ncon) and J, Jc (B,ncon,nz); Jc has the rows of inactive
+    inequalities (res_clamp == 0) zeroed.  Row/column order as in the reference: equality rows
+    knot-major then the x_0 block, inequality rows per knot [upper (m), lower (m)]; columns
+    per knot [x_t, u_t]."""
+    n = x0.shape[-1]
+    B, T, nt = xu.shape
+    m = nt - n
+    x, u = _split(xu, n)
+    x_next, (Jx, Ju) = dx_jac(x[:, :-1].reshape(-1, n), u[:, :-1].reshape(-1, m))
+    Jx = Jx.reshape(B, T - 1, n, n)
+    Ju = Ju.reshape(B, T - 1, n, m)
+    eq = torch.cat((x[:, 1:] - x_next.view(B, T - 1, n), x[:, :1] - x0[:, None]), 1).reshape(B, -1)
+    iq, iqc = dyn_res_ineq(x, u, x0, None, None, u_lower, u_upper)
+
+    neq, nineq, nz = T * n, 2 * T * m, T * nt
+    J = xu.new_zeros(B, neq + nineq, nz)
+    Jeq = J[:, :neq].view(B, T, n, T, nt)
+    ar = torch.arange(T - 1, device=xu.device)
+    Jeq[:, ar, :, ar, :n] = -Jx.permute(1, 0, 2, 3)            # -df/dx_t
+    Jeq[:, ar, :, ar, n:] = -Ju.permute(1, 0, 2, 3)            # -df/du_t
+    eye_n = torch.eye(n, dtype=xu.dtype, device=xu.device)
+    Jeq[:, ar, :, ar + 1, :n] = eye_n                          # +I on x_{t+1}
+    Jeq[:, T - 1, :, 0, :n] = eye_n                            # x_0 - x0
+    Jiq = J[:, neq:].view(B, T, 2, m, T, nt)
+    at = torch.arange(T, device=xu.device)
+    eye_m = torch.eye(m, dtype=xu.dtype, device=xu.device)
+    Jiq[:, at, 0, :, at, n:] = eye_m
+    Jiq[:, at, 1, :, at, n:] = -eye_m
+    Jc = J.clone()
+    Jc[:, neq:] *= (iqc > 0).to(xu.dtype)[..., None]
+    return torch.cat((eq, iq), 1), torch.cat((eq, iqc), 1), J, Jc
+
+
+def compute_cost(xu, Q, q, diag_cost=True):
+    """al_utils.py:339-351 (diagonal cost)."""
+    assert diag_cost
+    return (0.5 * (xu * Q * xu).sum(-1) + (q * xu).sum(-1)).sum(-1)
+
+
+def compute_cost_gradient(xu, Q, q, diag_cost=True):
+    """al_utils.py:354-360"""
+    assert diag_cost
+    return Q * xu + q
+
+
+def merit_function(xu, Q, q, dx, x0, lamda, rho, x_lower, x_upper, u_lower, u_upper, diag_cost=True):
+    """cost + rho/2 |res_clamp|^2 + lamda . res; a leading candidate axis (n_ls,B,T,nt) is
+    folded into the batch (al_utils.py:37-59)."""
+    if xu.dim() == 4:
+        k, B = xu.shape[:2]
+        rep = lambda t: t[None].expand(k, *t.shape).reshape(k * B, *t.shape[1:])
+        xu, x0, Q, q, rho, lamda = xu.reshape(k * B, *xu.shape[2:]), rep(x0), rep(Q), rep(q), rep(rho), rep(lamda)
+    B = xu.shape[0]
+    res, resc = dyn_res(xu, dx, x0, x_lower, x_upper, u_lower, u_upper)
+    return compute_cost(xu, Q, q) + 0.5 * rho[:, 0] * (resc * resc).sum(1) + (lamda * res).sum(1)
+
+
+class HessianTerms:
+    """diag(Qd) + rho Jc^T Jc, kept factored for the kernel (al_utils.py:96-102)."""
+
+    def __init__(self, Jc, Qd, rho):
+        self.Jc, self.Qd, self.rho = Jc, Qd, rho
+
+    def dense(self):
+        return torch.diag_embed(self.Qd) + self.rho[:, :, None] * torch.bmm(self.Jc.transpose(1, 2), self.Jc)
+
+
+def merit_grad_hessian(xu, Q, q, dx, dx_jac, x0, lamda, rho, x_lower, x_upper, u_lower, u_upper,
+                       diag_cost=True):
+    """grad = Q xu + q + J^T lamda + rho Jc^T res_clamp ; Hessian terms (al_utils.py:62-102)."""
+    B = xu.shape[0]
+    res, resc, J, Jc = constraint_jacobian(xu, x0, dx_jac, u_lower, u_upper)
+    grad = (compute_cost_gradient(xu, Q, q, diag_cost).reshape(B, -1)
+            + torch.bmm(lamda[:, None], J)[:, 0] + rho * torch.bmm(resc[:, None], Jc)[:, 0])
+    return grad, HessianTerms(Jc, Q.reshape(B, -1), rho)
+
+
+# ------------------------------------------------------------------------------------------
+# HIP calls
+# ------------------------------------------------------------------------------------------
+def newton_step(terms, grad):
+    """-> (update = -H^-1 grad, L, info) through dqp_al_newton_step."""
+    lib = _lib.load()
+    Jc = terms.Jc.detach().double().contiguous()
+    _need_gpu(Jc)
+    B, ncon, nz = Jc.shape
+    Qd = terms.Qd.detach().double().contiguous()
+    rho = terms.rho.detach().double().reshape(B).contiguous()
+    g = grad.detach().double().contiguous()
+    dev = Jc.device
+    upd = torch.empty(B, nz, dtype=torch.float64, device=dev)
+    L = torch.empty(B, nz, nz, dtype=torch.float64, device=dev)
+    info = torch.empty(B, dtype=torch.int32, device=dev)
+    dims = _lib.dqp_al_dims(B, nz, ncon, 0)
+    with torch.cuda.device(dev):
+        rc = lib.dqp_al_newton_step(ctypes.byref(dims), _ptr(Jc), _ptr(Qd), _ptr(rho), _ptr(g),
+                                    _ptr(upd), _ptr(L), _ptr(info), _stream(dev))
+    _lib.check(rc, "dqp_al_newton_step")
+    return upd, L, info
+
+
+def chol_solve_neg(L, rhs):
+    """-(L L^T)^-1 rhs through dqp_al_chol_solve."""
+    lib = _lib.load()
+    L = L.contiguous()
+    _need_gpu(L)
+    B, nz, _ = L.shape
+    r = rhs.detach().double().reshape(B, nz).contiguous()
+    out = torch.empty_like(r)
+    dims = _lib.dqp_al_dims(B, nz, 0, 0)
+    with torch.cuda.device(L.device):
+        rc = lib.dqp_al_chol_solve(ctypes.byref(dims), _ptr(L), _ptr(r), _ptr(out), _stream(L.device))
+    _lib.check(rc, "dqp_al_chol_solve")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+def line_search_newton(update, x_est, meritfnQ, merit, x0):
+    """20 candidate steps 2^-k evaluated as one batch; keep the argmin if it improves the merit
+    (al_utils.py:503-527).  The x_0 entries of every candidate are pinned to x0."""
+    B = x_est.shape[0]
+    n = x0.shape[-1]
+    steps = 2.0 ** (-torch.arange(N_LINESEARCH, device=x_est.device, dtype=torch.float32))
+    steps = steps[:, None].expand(N_LINESEARCH, B)
+    cand = x_est[None] + steps[:, :, None, None] * update[None]
+    cand[:, :, 0, :n] = x0[None]
+    vals = meritfnQ(cand).reshape(N_LINESEARCH, -1)
+    best, idx = vals.min(dim=0)
+    ar = torch.arange(B, device=x_est.device)
+    x_new = cand[idx, ar]
+    status = (best < merit).float()
+    keep = status.to(x_est.dtype)[:, None, None]
+    return keep * x_new + (1 - keep) * x_est, best, steps[idx, ar].mean().item(), status
+
+
+class NewtonAL(torch.autograd.Function):
+    """Four Newton steps on the augmented Lagrangian + implicit backward (al_utils.py:363-500)."""
+
+    @staticmethod
+    def forward(ctx, meritfn, dyn_fn, cost_fn, merit_grad_hessfn, xi, x0, lam, rho, Q, q,
+                threshold, eps, ls):
+        B, T, nt = xi.shape
+        x_est = xi
+        merit = meritfn(x_est, Q, q, lam, x0, rho)
+        chol_failed = False
+        status = None
+        terms = L = None
+        for _ in range(MAX_NEWTON_STEPS):          # merit_delta is pinned to 1000 (al_utils.py:453)
+            with torch.enable_grad():   # autograd-based dx_jac callables need a leaf (al_utils.py:409-411)
+                grad, terms = merit_grad_hessfn(x_est.detach().requires_grad_(True), Q, q, lam)
+            grad = grad.detach()
+            update = None
+            if not chol_failed:
+                upd, L, info = newton_step(terms, grad)
+                update = upd.reshape(B, T, nt).to(x_est.dtype)
+                if bool(torch.isnan(update).any()) or bool(torch.isinf(update).any()):
+                    chol_failed = True             # al_utils.py:419-423
+            if chol_failed:
+                update = -torch.linalg.solve(terms.dense(), grad.reshape(B, -1)).reshape(B, T, nt)
+            if ls:
+                x_est, merit, _, status = line_search_newton(
+                    update, x_est, lambda c: meritfn(c, Q, q, lam, x0, rho), merit, x0)
+            else:
+                x_est = x_est + update
+                merit = meritfn(x_est, Q, q, lam, x0, rho)
+        ctx.chol_failed = chol_failed
+        ctx.terms = terms
+        ctx.save_for_backward(L if L is not None else x_est.new_zeros(1), x_est)
+        if status is None:
+            status = torch.ones(B, device=xi.device)
+        return x_est, status
+
+    @staticmethod
+    def backward(ctx, x_grad, status_grad):
+        L, x = ctx.saved_tensors
+        B = x_grad.shape[0]
+        if ctx.chol_failed:
+            g = -torch.linalg.solve(ctx.terms.dense(), x_grad.reshape(B, -1)).reshape(x_grad.shape)
+        else:
+            g = chol_solve_neg(L, x_grad).reshape(x_grad.shape).to(x_grad.dtype)
+        # diagonal cost: dQ = g * x, dq = g                          al_utils.py:482-485
+        return (None,) * 8 + (g * x, g, None, None, None)
+
+
+def warm_start_al(x, lamda, rho, cost_start, cost_hist, lam_hist, rho_hist):
+    """Pick the multipliers / penalty of the first stored AL iterate whose cost was already below
+    the new starting cost; rescale lamda to that iterate's norm (al_utils.py:16-34)."""
+    B = x.shape[0]
+    idx = torch.max(cost_hist < cost_start[None], dim=0)[1]
+    ar = torch.arange(B, device=x.device)
+    ref = lam_hist[idx, ar]
+    lamda = lamda * (ref.norm(p=2, dim=-1) / lamda.norm(p=2, dim=-1)).unsqueeze(-1)
+    return lamda, rho_hist[idx, ar]

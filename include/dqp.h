@@ -153,6 +153,33 @@ int dqp_mpc_assemble_backward(const dqp_mpc_dims *dims, const double *dQ, const 
                               const double *dA, const double *db, double *dC, double *dc,
                               double *dF, double *df, double *dx0, void *stream);
 
+/* ------------------------------------------------------------ augmented-Lagrangian Newton */
+
+typedef struct dqp_al_dims {
+    int32_t nbatch;
+    int32_t nz;        /* T (n_state + n_ctrl) <= 128                                      */
+    int32_t ncon;      /* rows of the (clamped) constraint Jacobian: neq + nineq           */
+    int32_t reserved;
+} dqp_al_dims;
+
+/*
+ * Replaces, inside NewtonAL.forward (qpth/al_utils.py:403-427):
+ *   merit_hess = diag(Q) + rho * Jc^T Jc                  (al_utils.py:96-102, 176-178)
+ *   U, info = torch.linalg.cholesky_ex(merit_hess);  update = -cholesky_solve(grad, U)
+ * Jc (B,ncon,nz) is the clamped constraint Jacobian, Qdiag (B,nz), rho (B), grad (B,nz).
+ * Outputs: update (B,nz) (NaN when the factorisation fails, as the reference's NaN test at
+ * al_utils.py:419 expects), L (B,nz,nz) lower Cholesky factor with a zero upper part (or NULL),
+ * info (B) = 0 or the order of the first non-positive leading minor (cholesky_ex's info).
+ */
+int dqp_al_newton_step(const dqp_al_dims *dims, const double *Jc, const double *Qdiag,
+                       const double *rho, const double *grad, double *update, double *L,
+                       int32_t *info, void *stream);
+
+/* Replaces NewtonAL.backward's  -torch.cholesky_solve(x_grad, U)  (al_utils.py:477-480):
+ * out = -(L L^T)^-1 rhs. */
+int dqp_al_chol_solve(const dqp_al_dims *dims, const double *L, const double *rhs, double *out,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -21,7 +21,7 @@ from oracle import oracle
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "[RM]_*.npz")))
 DENSE = [c for c in CASES if "dense_zhat" in np.load(os.path.join(GOLDEN, c + ".npz")).files]
 
 ZT = dict(rtol=1e-6, atol=1e-8)

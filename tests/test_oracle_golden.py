@@ -15,7 +15,7 @@ import pytest
 from oracle import oracle
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "[RM]_*.npz")))
 
 
 def load(name):
@@ -86,3 +86,29 @@ def test_oracle_thread_count_invariant():
     a = oracle.qp_forward(d["Q"], d["p"], d["G"], d["h"], d["A"], d["b"], nthreads=1)
     b = oracle.qp_forward(d["Q"], d["p"], d["G"], d["h"], d["A"], d["b"], nthreads=4)
     assert np.array_equal(a["zhat"], b["zhat"]) and a["iters"] == b["iters"]
+
+
+# ------------------------------------------------------------------ AL / NewtonAL row
+AL_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "AL_*.npz")))
+
+
+@pytest.mark.parametrize("name", AL_CASES)
+def test_al_newton_step_oracle_matches_reference(name):
+    from oracle import al_oracle
+    g = load(name)
+    xu, x0 = g["ns_xu"], g["in_x0"]
+    res, resc, J, Jc = al_oracle.constraint_jacobian(xu, x0, g["in_u_lower"], g["in_u_upper"])
+    np.testing.assert_allclose(res, g["ns_res"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(resc, g["ns_res_clamp"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(J, g["ns_J"], rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(Jc, g["ns_Jc"], rtol=1e-12, atol=1e-13)
+    B = xu.shape[0]
+    lam = np.zeros((B, res.shape[1]))
+    grad = al_oracle.merit_grad(xu, g["ns_Qd"], g["in_c"], lam, g["ns_rho"], resc, J, Jc)
+    np.testing.assert_allclose(grad, g["ns_grad"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(al_oracle.hessian(Jc, g["ns_Qd"].reshape(B, -1), g["ns_rho"]), g["ns_H"],
+                               rtol=1e-12, atol=1e-12)
+    upd, L, info = al_oracle.newton_update(Jc, g["ns_Qd"].reshape(B, -1), g["ns_rho"], g["ns_grad"])
+    assert not info.any()
+    np.testing.assert_allclose(L, g["ns_L"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(upd, g["ns_update"], rtol=1e-9, atol=1e-11)
