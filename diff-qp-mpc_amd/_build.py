@@ -76,10 +76,28 @@ def _jobs():
     return jobs
 
 
+def _object_current(obj, cmd):
+    """An object is reused when it was produced by the same command line and is newer than its
+    own source and every header (the per-size objects take minutes; most edits touch one file)."""
+    stamp = obj + ".cmd"
+    if not (os.path.exists(obj) and os.path.exists(stamp)):
+        return False
+    with open(stamp) as f:
+        if f.read() != " ".join(cmd):
+            return False
+    src = cmd[cmd.index("-c") + 1]
+    deps = [src, os.path.join(os.path.dirname(HERE), "include", "dqp.h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    t = os.path.getmtime(obj)
+    return all(os.path.getmtime(d) <= t for d in deps)
+
+
 def build(force=False, verbose=False, max_parallel=None):
     if not force and not needs_build():
         return SO
     jobs = _jobs()
+    todo = [j for j in jobs if force or not _object_current(*j)]
+    all_jobs, jobs = jobs, todo
     max_parallel = max_parallel or max(1, min(len(jobs), (os.cpu_count() or 2)))
     pending, running = list(jobs), []
     while pending or running:
@@ -93,8 +111,10 @@ def build(force=False, verbose=False, max_parallel=None):
             for other, _ in running:
                 other.kill()
             raise subprocess.CalledProcessError(pr.returncode, cmd)
+        with open(cmd[-1] + ".cmd", "w") as f:
+            f.write(" ".join(cmd))
     subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] +
-                          [obj for obj, _ in jobs])
+                          [obj for obj, _ in all_jobs])
     return SO
 
 

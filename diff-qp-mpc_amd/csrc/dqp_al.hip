@@ -11,13 +11,18 @@
 // e.g. 100 x 100 x 120 for cartpole T=20), so it runs on the fp64 matrix cores:
 // v_mfma_f64_16x16x4_f64 tiles, lower-triangular tile pairs dealt round-robin to the 4 waves;
 // a lane's A and B operands are both plain coalesced reads of one row segment of Jc.
-// The Cholesky factor is right-looking in LDS on a 16x16 thread grid, the two triangular
-// solves run in place, and L is written out (zero upper part, like torch) for backward.
+// Jc is staged through LDS once (coalesced HBM reads); the factorisation (square-root-free,
+// H = M D M^T) keeps the matrix 16-cyclic in the registers of a 16x16 thread grid and only
+// passes the pivot column through LDS, one barrier per step; the two triangular solves run on
+// one wavefront with the vector in registers; L = M sqrt(D) is written out (zero upper part,
+// like torch) for backward.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
 
 #include "../../include/dqp.h"
+
+namespace dqp { extern unsigned long long *g_debug_stamps; }
 
 namespace {
 
@@ -27,126 +32,345 @@ struct AlP {
     const double *Jc, *Qd, *rho, *grad, *Lin, *rhs;
     double *update, *L, *out;
     int32_t *info;
-    int B, nz, ncon, ld;
+    int B, nz, ncon, ld, chunk_rows, flag_off;
+    unsigned long long *stamps;   // diagnostic (only read with -DDQP_STAMPS; tools/stamps_al.py)
 };
 
-// forward / backward substitution with the lower factor in LDS; b in LDS; all threads call.
-__device__ __forceinline__ void chol_solve_lds(const double *H, int ld, int nz, double *b, int tid)
+#ifdef DQP_STAMPS
+#define AL_STAMP(i) do { if (P.stamps && threadIdx.x == 0) P.stamps[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AL_STAMP(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ double bcast64(double v, int src)
 {
-    for (int k = 0; k < nz; ++k) {                       // L y = b
-        __syncthreads();
-        const double yk = b[k] / H[k * ld + k];
-        __syncthreads();
-        if (tid == 0) b[k] = yk;
-        for (int i = k + 1 + tid; i < nz; i += 256) b[i] = fma(-H[i * ld + k], yk, b[i]);
-    }
-    for (int k = nz - 1; k >= 0; --k) {                  // L^T x = y
-        __syncthreads();
-        const double xk = b[k] / H[k * ld + k];
-        __syncthreads();
-        if (tid == 0) b[k] = xk;
-        for (int i = tid; i < k; i += 256) b[i] = fma(-H[k * ld + i], xk, b[i]);
-    }
-    __syncthreads();
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma(fma(-d, r, 1.0), r, r);
+    return fma(fma(-d, r, 1.0), r, r);
+}
+
+// x <- (M D M^T)^-1 b  (UNIT: LDS holds the unit-lower M below the diagonal and sqrt(d) on it) or
+// x <- (L L^T)^-1 b    (!UNIT: LDS holds the Cholesky factor), on ONE wavefront, no barriers.
+// Element i of the vector lives on lane i & 63, slot i >> 6 (nz <= 128).  Columns are fetched
+// eight steps ahead of the substitution chain, so a step costs one readlane pair and one FMA.
+template <bool UNIT>
+__device__ __forceinline__ void wave_solve(const double *H, int ld, int nz, int zidx, double (&b)[2], int lane)
+{
+    double dg[2], rdg[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int i = lane + 64 * s;
+        dg[s] = i < nz ? H[i * ld + i] : 1.0;
+        rdg[s] = 1.0 / dg[s];
+    }
+    // branch-free: a masked entry reads the zero word the caller keeps at H[zidx]
+    constexpr int G = 8;
+    double mc[G][2], mn[G][2];
+    auto load_fwd = [&](double (&m)[G][2], int k0) {     // column k = k0 + u, rows i > k
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int k = k0 + u;
+            m[u][0] = H[(lane > k && lane < nz) ? lane * ld + k : zidx];
+            m[u][1] = H[(lane + 64 > k && lane + 64 < nz) ? (lane + 64) * ld + k : zidx];
+        }
+    };
+    auto load_bwd = [&](double (&m)[G][2], int k0) {     // row k = k0 - u, columns i < k
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int k = k0 - u;
+            m[u][0] = H[(lane < k && k < nz) ? k * ld + lane : zidx];
+            m[u][1] = H[(lane + 64 < k && k < nz) ? k * ld + lane + 64 : zidx];
+        }
+    };
+    // eight chained substitution steps on columns/rows k0 + sgn*u, pivots in slot S (k >> 6 == S)
+#define DQP_AL_CHAIN(S, SGN)                                                              \
+    _Pragma("unroll") for (int u = 0; u < G; ++u) {                                       \
+        const int k = k0 + (SGN) * u;                                                     \
+        double wk = bcast64(b[S], k & 63);                                                \
+        if (!UNIT) {                                                                      \
+            wk *= bcast64(rdg[S], k & 63);                                                \
+            b[S] = (lane + 64 * (S) == k) ? wk : b[S];                                    \
+        }                                                                                 \
+        b[0] = fma(-mc[u][0], wk, b[0]);                                                  \
+        b[1] = fma(-mc[u][1], wk, b[1]);                                                  \
+    }
+#define DQP_AL_ROTATE() _Pragma("unroll") for (int u = 0; u < G; ++u) { mc[u][0] = mn[u][0]; mc[u][1] = mn[u][1]; }
+    const int nzg = ((nz + G - 1) / G) * G, lo_end = min(nzg, 64);
+    load_fwd(mn, 0);
+    for (int k0 = 0; k0 < lo_end; k0 += G) { DQP_AL_ROTATE(); load_fwd(mn, k0 + G); DQP_AL_CHAIN(0, 1); }
+    for (int k0 = 64; k0 < nzg; k0 += G) { DQP_AL_ROTATE(); load_fwd(mn, k0 + G); DQP_AL_CHAIN(1, 1); }
+    if (UNIT) { b[0] *= rdg[0] * rdg[0]; b[1] *= rdg[1] * rdg[1]; }   // D^-1, d = (sqrt d)^2
+    load_bwd(mn, nzg - 1);
+    for (int k0 = nzg - 1; k0 >= 64; k0 -= G) { DQP_AL_ROTATE(); load_bwd(mn, k0 - G); DQP_AL_CHAIN(1, -1); }
+    for (int k0 = lo_end - 1; k0 >= 0; k0 -= G) { DQP_AL_ROTATE(); load_bwd(mn, k0 - G); DQP_AL_CHAIN(0, -1); }
+#undef DQP_AL_CHAIN
+#undef DQP_AL_ROTATE
+}
+
+#define TRI(a, b) ((a) * ((a) + 1) / 2 + (b))
+
+// lower-triangular 16x16 tiles in row-major order: tile t -> (ti, tj), tj <= ti
+__host__ __device__ constexpr int tile_row(int t) { int ti = 0; while ((ti + 1) * (ti + 2) / 2 <= t) ++ti; return ti; }
+__host__ __device__ constexpr int tile_col(int t) { return t - tile_row(t) * (tile_row(t) + 1) / 2; }
+
+// K-loop over one staged chunk for wave W: tiles W, W+4, ... accumulate in registers; the NT
+// column-block operands of a 4-row K step are fetched one step ahead of the MFMAs using them.
+template <int NT, int W, int NS>
+__device__ __forceinline__ void mfma_chunk(const double *Hs, int rows4, int kq, int l15, double4_t (&acc)[NS])
+{
+    constexpr int NZP = 16 * NT, NTILES = NT * (NT + 1) / 2;
+    const double *jr = Hs + kq * NZP + l15;
+    double opc[NT], opn[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) opn[c] = jr[16 * c];
+    for (int c0 = 0; c0 < rows4; c0 += 4) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) opc[c] = opn[c];
+        const double *jn = jr + (c0 + 4 < rows4 ? c0 + 4 : c0) * NZP;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) opn[c] = jn[16 * c];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (W + 4 * s < NTILES)
+                acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(opc[tile_row(W + 4 * s)], opc[tile_col(W + 4 * s)],
+                                                              acc[s], 0, 0, 0);
+    }
+}
+
+// C/D layout of the f64 16x16x4 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+template <int NT, int W, int NS>
+__device__ __forceinline__ void store_tiles(double *H, int ld, int nz, double rho, int kq, int l15,
+                                            const double4_t (&acc)[NS])
+{
+    constexpr int NTILES = NT * (NT + 1) / 2;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (W + 4 * s >= NTILES) continue;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int row = 16 * tile_row(W + 4 * s) + kq + 4 * rg, col = 16 * tile_col(W + 4 * s) + l15;
+            if (row < nz && col <= row) H[row * ld + col] = rho * acc[s][rg];
+        }
+    }
+}
+
+// One problem per 256-thread workgroup; NT = ceil(nz / 16) is a template parameter so every
+// register-array loop (MFMA tiles, the 16-cyclic factor) is fully unrolled at its true size.
+template <int NT>
 __global__ __launch_bounds__(256) void al_newton_kernel(AlP P)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    constexpr int NZP = 16 * NT, NS = (NT * (NT + 1) / 2 + 3) / 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ty = tid >> 4, tx = tid & 15;
     const int nz = P.nz, ncon = P.ncon, ld = P.ld;
     const long long prob = blockIdx.x;
-    double *H = sm;                    // nzp x ld
-    double *bvec = sm + (size_t)((nz + 15) & ~15) * ld;
-    // failure flag in the dynamic region (a static __shared__ would shift its base off 16 B)
-    volatile double *s_info = bvec + ((nz + 15) & ~15);
-    if (tid == 0) *s_info = 0.0;
+    double *H = sm;                                   // nz x ld
+    if (tid == 0) sm[P.flag_off + 1] = 0.0;           // the zero word masked solve loads read
+    AL_STAMP(0);
+    // diagonal of the cost Hessian for the 16-cyclic owner of (i, i): threads with ty == tx
+    double qd[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) qd[a] = (ty == tx && ty + 16 * a < nz) ? P.Qd[prob * nz + ty + 16 * a] : 0.0;
 
-    // ---- H = diag(Qd) + rho * Jc^T Jc with fp64 MFMA tiles ---------------------------------
+    // ---- H = diag(Qd) + rho * Jc^T Jc ---------------------------------------------------------
+    // Jc is staged through LDS (the not-yet-written H region) in zero-padded chunks of CH rows,
+    // read from HBM exactly once with coalesced loads; each wave owns up to 9 lower-triangular
+    // 16x16 output tiles whose fp64 MFMA accumulators stay in registers across the whole K loop.
     const double *J = P.Jc + prob * (long long)ncon * nz;
     const double rho = P.rho[prob];
-    const int nt = (nz + 15) >> 4;
-    int tile = 0;
-    for (int ti = 0; ti < nt; ++ti)
-        for (int tj = 0; tj <= ti; ++tj, ++tile) {
-            if ((tile & 3) != wave) continue;
-            double4_t acc = {0.0, 0.0, 0.0, 0.0};
-            const int ia = 16 * ti + (lane & 15), jb = 16 * tj + (lane & 15), kq = lane >> 4;
-            for (int c0 = 0; c0 < ncon; c0 += 4) {
-                const int c = c0 + kq;
-                const bool cv = c < ncon;
-                const double a = (cv && ia < nz) ? J[(long long)c * nz + ia] : 0.0;   // A[i][k] = Jc[k][i]
-                const double b = (cv && jb < nz) ? J[(long long)c * nz + jb] : 0.0;   // B[k][j] = Jc[k][j]
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-            }
-            // C/D layout of the f64 16x16x4 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg
+    const int CH = P.chunk_rows;
+    double4_t acc[NS];
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int row = 16 * ti + (lane >> 4) + 4 * rg, col = 16 * tj + (lane & 15);
-                if (row < nz && col < nz) {
-                    double v = rho * acc[rg];
-                    if (row == col) v += P.Qd[prob * nz + row];
-                    H[row * ld + col] = v;
+    for (int s = 0; s < NS; ++s) acc[s] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int l15 = lane & 15, kq = lane >> 4;
+    for (int cb = 0; cb < ncon; cb += CH) {
+        const int rows = min(CH, ncon - cb), rows4 = (rows + 3) & ~3;
+        __syncthreads();
+        // wave w stages rows w, w+4, ...; a lane covers columns lane and lane+64; 16 loads in flight
+        for (int r0 = wave; r0 < rows4; r0 += 32) {
+            double v[8][2];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int rr = r0 + 4 * u, cc = lane + 64 * s;
+                    v[u][s] = (rr < rows && cc < nz) ? J[(long long)(cb + rr) * nz + cc] : 0.0;
+                }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int rr = r0 + 4 * u, cc = lane + 64 * s;
+                    if (rr < rows4 && cc < NZP) H[rr * NZP + cc] = v[u][s];
+                }
+        }
+        __syncthreads();
+        switch (wave) {
+        case 0: mfma_chunk<NT, 0, NS>(H, rows4, kq, l15, acc); break;
+        case 1: mfma_chunk<NT, 1, NS>(H, rows4, kq, l15, acc); break;
+        case 2: mfma_chunk<NT, 2, NS>(H, rows4, kq, l15, acc); break;
+        default: mfma_chunk<NT, 3, NS>(H, rows4, kq, l15, acc); break;
+        }
+    }
+    __syncthreads();
+    AL_STAMP(1);
+    switch (wave) {
+    case 0: store_tiles<NT, 0, NS>(H, ld, nz, rho, kq, l15, acc); break;
+    case 1: store_tiles<NT, 1, NS>(H, ld, nz, rho, kq, l15, acc); break;
+    case 2: store_tiles<NT, 2, NS>(H, ld, nz, rho, kq, l15, acc); break;
+    default: store_tiles<NT, 3, NS>(H, ld, nz, rho, kq, l15, acc); break;
+    }
+    __syncthreads();
+    AL_STAMP(2);
+
+    // ---- factorisation in registers --------------------------------------------------------------
+    // Thread (ty, tx) of the 16 x 16 grid owns the 16-cyclic elements H[ty + 16a][tx + 16b],
+    // b <= a.  Step k: every thread picks up the pivot and its <= NT row and <= NT column
+    // operands from the published column k (double-buffered in LDS, one barrier per step) and
+    // applies the rank-1 update to its registers -- next pivot column first, so its owners
+    // publish it before the bulk of the update (look-ahead).  Columns stay unscaled (c_ik) with
+    // the pivot d_k on the diagonal: H = M D M^T, M_ik = c_ik / d_k.
+    double hr[NT * (NT + 1) / 2];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const int row = ty + 16 * a, col = tx + 16 * b;
+            hr[TRI(a, b)] = (row < nz && col <= row) ? H[row * ld + col] : 0.0;
+            if (a == b) hr[TRI(a, b)] += qd[a];
+        }
+    __syncthreads();
+    double *colbuf = sm;                 // 2 x 128 doubles, aliases the (now unused) H region
+    double dcol[NT];
+#pragma unroll
+    for (int b = 0; b < NT; ++b) dcol[b] = 1.0;
+    int firstbad = 0;                    // torch.linalg.cholesky_ex: info = first non-positive minor
+    if (tx == 0) {
+#pragma unroll
+        for (int a = 0; a < NT; ++a) colbuf[ty + 16 * a] = hr[TRI(a, 0)];
+    }
+#pragma unroll
+    for (int kb = 0; kb < NT; ++kb) {
+        const int kend = min(16, nz - 16 * kb);
+        for (int kr = 0; kr < kend; ++kr) {
+            const int k = 16 * kb + kr;
+            const double *cbuf = colbuf + (k & 1) * 128;
+            double *nbuf = colbuf + ((k + 1) & 1) * 128;
+            __syncthreads();
+            const double d = cbuf[k];
+            double r[NT], c[NT];
+#pragma unroll
+            for (int a = kb; a < NT; ++a) { r[a] = cbuf[ty + 16 * a]; c[a] = cbuf[tx + 16 * a]; }
+            firstbad = (firstbad == 0 && !(d > 0.0)) ? k + 1 : firstbad;
+            const double nrd = -rcp_nr(d);
+            if (tx == kr) dcol[kb] = d;
+            r[kb] = ty > kr ? r[kb] : 0.0;
+            c[kb] = tx > kr ? c[kb] : 0.0;
+#pragma unroll
+            for (int a = kb; a < NT; ++a) r[a] *= nrd;
+#pragma unroll
+            for (int a = kb; a < NT; ++a) hr[TRI(a, kb)] = fma(r[a], c[kb], hr[TRI(a, kb)]);
+            if (kr < 15) {
+                if (tx == kr + 1) {
+#pragma unroll
+                    for (int a = kb; a < NT; ++a) nbuf[ty + 16 * a] = hr[TRI(a, kb)];
                 }
             }
+            if (kb + 1 < NT) {
+#pragma unroll
+                for (int a = kb + 1; a < NT; ++a) hr[TRI(a, kb + 1)] = fma(r[a], c[kb + 1], hr[TRI(a, kb + 1)]);
+                if (kr == 15) {
+                    if (tx == 0) {
+#pragma unroll
+                        for (int a = kb + 1; a < NT; ++a) nbuf[ty + 16 * a] = hr[TRI(a, kb + 1)];
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = kb + 2; b < NT; ++b)
+#pragma unroll
+                for (int a = b; a < NT; ++a) hr[TRI(a, b)] = fma(r[a], c[b], hr[TRI(a, b)]);
         }
-    for (int i = tid; i < nz; i += 256) bvec[i] = -P.grad[prob * nz + i];
-    __syncthreads();
-
-    // ---- right-looking Cholesky (lower) on a 16 x 16 thread grid ----------------------------
-    const int ty = tid >> 4, tx = tid & 15;
-    for (int k = 0; k < nz; ++k) {
-        const double d = H[k * ld + k];
-        __syncthreads();
-        if (!(d > 0.0)) {                      // torch.linalg.cholesky_ex: info = first bad minor
-            if (tid == 0 && *s_info == 0.0) *s_info = (double)(k + 1);
-            break;
-        }
-        const double sq = sqrt(d), r = 1.0 / sq;
-        if (tid == 0) H[k * ld + k] = sq;
-        for (int i = k + 1 + tid; i < nz; i += 256) H[i * ld + k] *= r;
-        __syncthreads();
-        for (int i = k + 1 + ty; i < nz; i += 16) {
-            const double lik = H[i * ld + k];
-            for (int j = k + 1 + tx; j <= i; j += 16) H[i * ld + j] = fma(-lik, H[j * ld + k], H[i * ld + j]);
-        }
-        __syncthreads();
     }
     __syncthreads();
-    const int info = (int)*s_info;
-    if (info == 0) chol_solve_lds(H, ld, nz, bvec, tid);
+    AL_STAMP(3);
+    // LDS <- unit-lower M (strictly below the diagonal) and sqrt(d) on the diagonal
+    {
+        double rdc[NT], sdc[NT];
+#pragma unroll
+        for (int b = 0; b < NT; ++b) { rdc[b] = 1.0 / dcol[b]; sdc[b] = sqrt(dcol[b]); }
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+                const int row = ty + 16 * a, col = tx + 16 * b;
+                if (row < nz && col <= row) H[row * ld + col] = col == row ? sdc[b] : hr[TRI(a, b)] * rdc[b];
+            }
+    }
+    __syncthreads();
+    const int info = firstbad;
+    AL_STAMP(4);
 
-    // ---- outputs ------------------------------------------------------------------------------
-    const double nanv = __longlong_as_double(0x7ff8000000000000LL);
-    for (int i = tid; i < nz; i += 256) P.update[prob * nz + i] = info == 0 ? bvec[i] : nanv;
-    if (P.L) {
+    // ---- wave 0 solves while waves 1-3 write the factor out -------------------------------------
+    if (wave == 0) {
+        double b[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) b[s] = (lane + 64 * s < nz) ? -P.grad[prob * nz + lane + 64 * s] : 0.0;
+        if (info == 0) wave_solve<true>(H, ld, nz, P.flag_off + 1, b, lane);
+        const double nanv = __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            if (lane + 64 * s < nz) P.update[prob * nz + lane + 64 * s] = info == 0 ? b[s] : nanv;
+        if (lane == 0 && P.info) P.info[prob] = info;
+        AL_STAMP(5);
+    } else if (P.L) {                     // Cholesky factor L_ik = M_ik sqrt(d_k), zero upper part
         double *Lo = P.L + prob * (long long)nz * nz;
-        for (int e = tid; e < nz * nz; e += 256) {
-            const int i = e / nz, j = e - i * nz;
-            Lo[e] = j <= i ? H[i * ld + j] : 0.0;
-        }
+        double sd[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) sd[s] = H[min(lane + 64 * s, nz - 1) * (ld + 1)];
+        for (int i = wave - 1; i < nz; i += 3)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int j = lane + 64 * s;
+                if (j < nz) Lo[i * nz + j] = j < i ? H[i * ld + j] * sd[s] : (j == i ? sd[s] : 0.0);
+            }
     }
-    if (tid == 0 && P.info) P.info[prob] = info;
 }
 
-// out = -(L L^T)^-1 rhs   (NewtonAL.backward, al_utils.py:477-480)
+// out = -(L L^T)^-1 rhs   (NewtonAL.backward, al_utils.py:477-480); block loads L, wave 0 solves
 __global__ __launch_bounds__(256) void al_chol_solve_kernel(AlP P)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nz = P.nz, ld = P.ld;
     const long long prob = blockIdx.x;
     double *H = sm;
-    double *bvec = sm + (size_t)((nz + 15) & ~15) * ld;
     const double *Li = P.Lin + prob * (long long)nz * nz;
-    for (int e = tid; e < nz * nz; e += 256) {
-        const int i = e / nz, j = e - i * nz;
-        H[i * ld + j] = Li[e];
-    }
-    for (int i = tid; i < nz; i += 256) bvec[i] = -P.rhs[prob * nz + i];
+    if (tid == 0) sm[P.flag_off + 1] = 0.0;
+    for (int i = wave; i < nz; i += 4)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int j = lane + 64 * s;
+            if (j <= i) H[i * ld + j] = Li[i * nz + j];
+        }
     __syncthreads();
-    chol_solve_lds(H, ld, nz, bvec, tid);
-    for (int i = tid; i < nz; i += 256) P.out[prob * nz + i] = bvec[i];
+    if (tid >= 64) return;
+    double b[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) b[s] = (lane + 64 * s < nz) ? -P.rhs[prob * nz + lane + 64 * s] : 0.0;
+    wave_solve<false>(H, ld, nz, P.flag_off + 1, b, lane);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+        if (lane + 64 * s < nz) P.out[prob * nz + lane + 64 * s] = b[s];
 }
 
 int fill(const dqp_al_dims *d, AlP &P, size_t &lds)
@@ -154,21 +378,30 @@ int fill(const dqp_al_dims *d, AlP &P, size_t &lds)
     if (!d || d->nbatch < 0 || d->nz <= 0 || d->ncon < 0) return DQP_ERR_BAD_ARG;
     if (d->nz > 128) return DQP_ERR_TOO_LARGE;
     P.B = d->nbatch; P.nz = d->nz; P.ncon = d->ncon;
-    P.ld = d->nz | 1;
-    lds = ((size_t)((d->nz + 15) & ~15) * P.ld + ((d->nz + 15) & ~15) + 2) * sizeof(double);
+    P.stamps = dqp::g_debug_stamps;
+    // LDS: the nz x nz factor (ld = nz | 1: 80,800 B at nz = 100, so two problems share a CU); the
+    // same region first stages Jc in chunks of `chunk_rows` zero-padded rows of 16*ceil(nz/16).
+    P.ld = d->nz | 1;                 // odd leading dimension: conflict-free column reads
+    const int nzp = (d->nz + 15) & ~15;
+    size_t hd = (size_t)d->nz * P.ld;
+    if (hd < (size_t)4 * nzp) hd = (size_t)4 * nzp;
+    if (hd < 256) hd = 256;           // the double-buffered pivot column of the factorisation
+    P.chunk_rows = (int)((hd / nzp) & ~(size_t)3);
+    P.flag_off = (int)hd;
+    lds = (hd + 2) * sizeof(double);
     if (lds > 160 * 1024 - 64) return DQP_ERR_TOO_LARGE;
     return DQP_OK;
 }
 
 template <typename K>
-int launch(K kernel, const AlP &P, size_t lds, void *stream)
+int launch(K kernel, const AlP &P, size_t lds, void *stream, int threads = 256)
 {
     if (P.B == 0) return DQP_OK;
     if (lds > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DQP_ERR_LAUNCH;
-    hipLaunchKernelGGL(kernel, dim3(P.B), dim3(256), lds, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(kernel, dim3(P.B), dim3(threads), lds, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
@@ -187,7 +420,16 @@ dqp_al_newton_step(const dqp_al_dims *dims, const double *Jc, const double *Qdia
     if (P.B == 0) return DQP_OK;
     if ((!Jc && P.ncon > 0) || !Qdiag || !rho || !grad || !update) return DQP_ERR_BAD_ARG;
     P.Jc = Jc; P.Qd = Qdiag; P.rho = rho; P.grad = grad; P.update = update; P.L = L; P.info = info;
-    return launch(al_newton_kernel, P, lds, stream);
+    switch ((P.nz + 15) / 16) {
+    case 1: return launch(al_newton_kernel<1>, P, lds, stream);
+    case 2: return launch(al_newton_kernel<2>, P, lds, stream);
+    case 3: return launch(al_newton_kernel<3>, P, lds, stream);
+    case 4: return launch(al_newton_kernel<4>, P, lds, stream);
+    case 5: return launch(al_newton_kernel<5>, P, lds, stream);
+    case 6: return launch(al_newton_kernel<6>, P, lds, stream);
+    case 7: return launch(al_newton_kernel<7>, P, lds, stream);
+    default: return launch(al_newton_kernel<8>, P, lds, stream);
+    }
 }
 
 __attribute__((visibility("default"))) int
