@@ -48,6 +48,7 @@ template <class C> struct State {
     double Ah[C::SE][C::N];      // At = L1^-1 A Lq^-T (orthonormal rows)
     double rdq[C::SN];           // 1 / diag(Lq)
     double rd1[C::SE];           // 1 / diag(L1)
+    double rdiag[C::SM];         // diag(R) of the lane's rows (factor_T rewrites the LDS copy)
     int status;
 };
 
@@ -201,17 +202,32 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         }
     }
     __syncthreads();   // factor_T reads R[j][i] written by the lane that owns row j
+#pragma unroll
+    for (int s = 0; s < SM; ++s) {
+        const int i = r + 16 * s;
+        const double v = (lds + C::oR)[tri(i < M ? i : M - 1) + (i < M ? i : M - 1)];
+        st.rdiag[s] = i < M ? v : 0.0;
+    }
     __builtin_amdgcn_sched_barrier(0);
     STAMP(P, 5);
 }
 
 // T = R + diag(dinv) (full square, row-distributed) from the packed triangle in LDS, then LU.
+// Each lane first rewrites its own diagonal entries of the LDS triangle with R_ii + dinv_i (only
+// the owning lane ever reads them back), so the load needs no per-element diagonal select.
 template <class C>
-__device__ __forceinline__ void factor_T(const double *lds, double (&T)[C::SM][C::M],
-                                         const double (&dinv)[C::SM], double (&rdu)[C::SM], int r)
+__device__ __forceinline__ void factor_T(double *lds, double (&T)[C::SM][C::M],
+                                         const double (&rdiag)[C::SM], const double (&dinv)[C::SM],
+                                         double (&rdu)[C::SM], int r)
 {
     constexpr int M = C::M, SM = C::SM;
-    const double *Rp = lds + C::oR;
+    double *Rp = lds + C::oR;
+#pragma unroll
+    for (int s = 0; s < SM; ++s) {
+        const int i = r + 16 * s;
+        double *dst = i < M ? Rp + tri(i) + i : lds + C::oDummy + r;
+        *dst = rdiag[s] + dinv[s];
+    }
 #pragma unroll
     for (int s = 0; s < SM; ++s) {
         const int i = r + 16 * s;
@@ -222,9 +238,8 @@ __device__ __forceinline__ void factor_T(const double *lds, double (&T)[C::SM][C
             if (16 * s > j) off = tri(ic) + j;                          // all rows below column j
             else if (16 * s + 15 < j) off = tri(j) + ic;                // all rows above
             else off = (j <= ic) ? tri(ic) + j : tri(j) + ic;
-            double v = Rp[off];
-            if (i >= M) v = (i == j) ? 1.0 : 0.0;
-            T[s][j] = (i == j) ? v + dinv[s] : v;
+            const double v = Rp[off];
+            T[s][j] = (16 * s + 15 >= M) ? mask_hi(v, i < M) : v;       // pad rows: ~zero rows
         }
     }
     lu_rows<SM, M>(T, rdu, r);
@@ -281,11 +296,6 @@ __device__ __forceinline__ void kkt_xy(const State<C> &st, const double (&rxh)[C
     }
 }
 
-__device__ __forceinline__ double ratio(double v, double dv, bool active)
-{
-    return (active && dv < 0.0) ? -v / dv : INFINITY;
-}
-
 template <class C>
 __global__ __launch_bounds__(64) void forward_kernel(KParams P)
 {
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         for (int s = 0; s < SE; ++s) mb[s] = -bt[s];
         kkt_rhs<C>(st, ph, zero, mh, mb, wz, r);
         __builtin_amdgcn_sched_barrier(0);
-        factor_T<C>(lds, T, one, rdu, r);
+        factor_T<C>(lds, T, st.rdiag, one, rdu, r);
         lu_solve<SM, M>(T, rdu, wz, r);
         __builtin_amdgcn_sched_barrier(0);
         double gt0[SN], at0[SN];
@@ -407,7 +417,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             }
         }
         sz = row_sum(sz); nz2 = row_sum(nz2); nx2 = row_sum(nx2); ny2 = row_sum(ny2);
-        const double mu = fabs(sz / M);
+        const double mu = fabs(sz * (1.0 / M));
         const double resid = sqrt(nz2) + sqrt(ny2) + sqrt(nx2) + M * mu;
         // best-iterate tracking / per-problem termination (uniform inside a DPP row)
         if (!done) {
@@ -434,24 +444,34 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         kkt_rhs<C>(st, rxh, s_, rz, ryt, dza, r);
         __builtin_amdgcn_sched_barrier(0);
         // phase 2 (T live, Gh/At idle): factor + affine and corrector solves   batch.py:110-181
+        // Divisions by s and z go through one reciprocal each per iteration; the step length
+        // min_i(-v_i/dv_i | dv_i < 0) (get_step, batch.py:211-214) is 1 / max_i(-dv_i/v_i), so the
+        // row reduction runs on products and only the row-uniform result is inverted.  Pad lanes
+        // carry zero reciprocals (and exact zeros out of lu_solve), so nothing else is guarded.
         double dinv[SM];
 #pragma unroll
-        for (int s = 0; s < SM; ++s) dinv[s] = inM[s] ? s_[s] / z[s] : 0.0;   // 1/d, d = z/s
-        factor_T<C>(lds, T, dinv, rdu, r);
+        for (int s = 0; s < SM; ++s) dinv[s] = inM[s] ? s_[s] * frcp(z[s]) : 0.0;   // 1/d, d = z/s
+        factor_T<C>(lds, T, st.rdiag, dinv, rdu, r);
         if (it == 1) STAMP(P, 10);
         lu_solve<SM, M>(T, rdu, dza, r);
-        double am = INFINITY;
+        double rzv[SM], rsv[SM];           // formed only now: not live across the factorisation
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
-            dsa[s] = inM[s] ? (-z[s] - dza[s]) * dinv[s] : 0.0;
-            am = fmin(am, fmin(ratio(z[s], dza[s], inM[s]), ratio(s_[s], dsa[s], inM[s])));
+            rzv[s] = inM[s] ? frcp(z[s]) : 0.0;
+            rsv[s] = inM[s] ? frcp(s_[s]) : 0.0;
         }
-        double alpha = fmin(row_min(am), 1.0);
+        double tm = 0.0;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            dsa[s] = (-z[s] - dza[s]) * dinv[s];
+            tm = fmax(tm, fmax(-dza[s] * rzv[s], -dsa[s] * rsv[s]));
+        }
+        double alpha = frcp(fmax(row_max(tm), 1.0));                           // min(step, 1)
         if (it == 1) STAMP(P, 11);
         double t3 = 0.0;
 #pragma unroll
         for (int s = 0; s < SM; ++s)
-            t3 += inM[s] ? (s_[s] + alpha * dsa[s]) * (z[s] + alpha * dza[s]) : 0.0;
+            t3 = fma(fma(alpha, dsa[s], s_[s]), fma(alpha, dza[s], z[s]), t3);
         t3 = row_sum(t3);
         double sig = t3 / sz;
         sig = sig * sig * sig;
@@ -459,23 +479,23 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         double rsc[SM], dzc[SM], dz[SM], ds[SM];
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
-            rsc[s] = inM[s] ? (-mu * sig + dsa[s] * dza[s]) / s_[s] : 0.0;
+            rsc[s] = fma(dsa[s], dza[s], -mu * sig) * rsv[s];
             dzc[s] = -rsc[s] * dinv[s];
         }
         lu_solve<SM, M>(T, rdu, dzc, r);
         if (it == 1) STAMP(P, 12);
-        am = INFINITY;
+        tm = 0.0;
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
             dz[s] = dza[s] + dzc[s];
-            ds[s] = dsa[s] + (inM[s] ? (-rsc[s] - dzc[s]) * dinv[s] : 0.0);
-            am = fmin(am, fmin(ratio(z[s], dz[s], inM[s]), ratio(s_[s], ds[s], inM[s])));
+            ds[s] = fma(-rsc[s] - dzc[s], dinv[s], dsa[s]);
+            tm = fmax(tm, fmax(-dz[s] * rzv[s], -ds[s] * rsv[s]));
         }
         __builtin_amdgcn_sched_barrier(0);
         // phase 3 (Gh/At live, T dead): x / y part of the combined direction
         double dxh[SN], dyt[SE], gtd[SN], atd[SN];
         kkt_xy<C>(st, rxh, ryt, dz, dxh, dyt, gtd, atd, r);
-        alpha = fmin(0.999 * row_min(am), 1.0);
+        alpha = frcp(fmax(row_max(tm) * (1.0 / 0.999), 1.0));                  // min(0.999 step, 1)
         if (it == 1) STAMP(P, 13);
         if (it == 0) STAMP(P, 8);
         if (!done) {
@@ -572,7 +592,7 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P)
     __builtin_amdgcn_sched_barrier(0);
     {
         double T[SM][M], rdu[SM];
-        factor_T<C>(lds, T, dinv, rdu, r);
+        factor_T<C>(lds, T, st.rdiag, dinv, rdu, r);
         lu_solve<SM, M>(T, rdu, dlam, r);
     }
     __builtin_amdgcn_sched_barrier(0);

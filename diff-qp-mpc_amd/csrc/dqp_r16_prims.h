@@ -49,6 +49,22 @@ __device__ __forceinline__ double row_min(double v)
     return v;
 }
 
+__device__ __forceinline__ double row_max(double v)
+{
+    v = fmax(v, dppd<0x128>(v)); v = fmax(v, dppd<0x124>(v));
+    v = fmax(v, dppd<0x122>(v)); v = fmax(v, dppd<0x121>(v));
+    return v;
+}
+
+// keep ? v : (v with its high word cleared).  The cleared value is 0 or a positive denormal
+// below 2^-1042, which every FMA on normal-range data absorbs exactly -- one v_cndmask instead of
+// the two a full 64-bit select costs (these kernels issue one instruction per 4 cycles, so
+// predication selects were ~20 % of the PDIPM iteration).
+__device__ __forceinline__ double mask_hi(double v, bool keep)
+{
+    return __hiloint2double(keep ? __double2hiint(v) : 0, __double2loint(v));
+}
+
 // full-precision reciprocal / reciprocal square root from the hardware estimates + 2 Newton steps
 __device__ __forceinline__ double frcp(double d)
 {
@@ -209,7 +225,7 @@ __device__ __forceinline__ void lu_rows(double (&T)[S][N], double (&rdu)[S], int
         for (int s = 0; s < S; ++s) {
             if (16 * s + 15 <= k) l[s] = 0.0;
             else if (16 * s > k) { l[s] = T[s][k] * rp; T[s][k] = l[s]; }
-            else { const bool a = r > lk; l[s] = a ? T[s][k] * rp : 0.0; T[s][k] = a ? l[s] : T[s][k]; }
+            else { const bool a = r > lk; l[s] = mask_hi(T[s][k], a) * rp; T[s][k] = a ? l[s] : T[s][k]; }
         }
 #pragma unroll
         for (int j = k + 1; j < N; ++j) {
@@ -221,7 +237,9 @@ __device__ __forceinline__ void lu_rows(double (&T)[S][N], double (&rdu)[S], int
     }
 }
 
-// b <- T^-1 b with the LU above.
+// b <- T^-1 b with the LU above.  In the U sweep a lane keeps its own y_k unscaled (the pivot
+// scaling is applied to the broadcast copy and, once, to the whole vector at the end), so the
+// only per-step predication is the one-instruction triangle mask.
 template <int S, int N>
 __device__ __forceinline__ void lu_solve(const double (&T)[S][N], const double (&rdu)[S],
                                          double (&b)[S], int r)
@@ -234,7 +252,7 @@ __device__ __forceinline__ void lu_solve(const double (&T)[S][N], const double (
         for (int s = 0; s < S; ++s) {
             if (16 * s + 15 <= k) continue;
             if (16 * s > k) b[s] = fma(-T[s][k], bk, b[s]);
-            else b[s] = fma(r > lk ? -T[s][k] : 0.0, bk, b[s]);
+            else b[s] = fma(-mask_hi(T[s][k], r > lk), bk, b[s]);
         }
     }
 #pragma unroll
@@ -245,9 +263,11 @@ __device__ __forceinline__ void lu_solve(const double (&T)[S][N], const double (
         for (int s = 0; s < S; ++s) {
             if (16 * s > k) continue;
             if (16 * s + 15 < k) b[s] = fma(-T[s][k], xk, b[s]);
-            else b[s] = (r == lk) ? xk : fma(r < lk ? -T[s][k] : 0.0, xk, b[s]);
+            else b[s] = fma(-mask_hi(T[s][k], r < lk), xk, b[s]);
         }
     }
+#pragma unroll
+    for (int s = 0; s < S; ++s) b[s] *= rdu[s];
 }
 
 // b <- L^-1 b, L lower triangular row-distributed in registers (rd = reciprocal diagonal)
@@ -300,7 +320,7 @@ __device__ __forceinline__ void tri_mv(const double *P, const double (&x)[S], do
             const int i = r + 16 * s;
             const int ic = i < N ? i : N - 1;
             const double v = P[tri(ic) + (j <= ic ? j : 0)];
-            y[s] = fma((j <= i && i < N) ? v : 0.0, xb, y[s]);
+            y[s] = fma(mask_hi(v, j <= i && i < N), xb, y[s]);
         }
     }
 }
