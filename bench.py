@@ -92,6 +92,8 @@ class HotPath:
         self.dA = torch.empty(B, NEQ, NZ, **kw); self.db = torch.empty(B, NEQ, **kw)
         self.dims = _lib.dqp_dims(B, NZ, NINEQ, NEQ, NZ * NZ, NZ, NINEQ * NZ, NINEQ, NEQ * NZ, NEQ)
         self.opts = _lib.dqp_opts(1e-12, 1e-10, 20, 3, 0, 0)
+        wsb = int(self.lib.dqp_workspace_bytes(ctypes.byref(self.dims)))
+        self.ws = torch.empty(max(wsb // 8, 1), **kw)            # caller-owned scratch (include/dqp.h)
         self.stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         self.fargs = [P(t) for t in (self.Q, self.p, self.G, self.h, self.A, self.b, self.zhat,
@@ -100,10 +102,11 @@ class HotPath:
                                      self.slack, self.ct, self.dQ, self.dp, self.dG, self.dh,
                                      self.dA, self.db)]
         self.null = ctypes.c_void_p(0)
+        self.wsp = P(self.ws) if wsb > 0 else self.null
 
     def forward(self):
         rc = self.lib.dqp_qp_forward(ctypes.byref(self.dims), ctypes.byref(self.opts), *self.fargs,
-                                     self.null, self.stream)
+                                     self.wsp, self.stream)
         if rc:
             raise RuntimeError("dqp_qp_forward rc=%d" % rc)
 

@@ -22,8 +22,8 @@ R16_SIZES = [
     (25, 10, 20),   # n=4 m=1 T=5 (cartpole-1)
     (10, 5, 3), (12, 8, 0),   # small test sizes (with / without equalities)
 ]
-# opt-in reduced-Hessian forward (csrc/dqp_r16n.hip, DQP_FLAG_REDUCED_HESSIAN)
-R16N_SIZES = [(30, 30, 15)]
+# null-space form of the forward kernel (csrc/dqp_r16n.hip): every size above with equalities
+R16N_SIZES = [s for s in R16_SIZES if s[2] > 0]
 
 PLAIN_SOURCES = ["dqp_pdipm.hip", "dqp_mpc.hip", "dqp_al.hip"]
 SOURCES = PLAIN_SOURCES + ["dqp_r16.hip", "dqp_r16n.hip", "dqp_dispatch.hip"]

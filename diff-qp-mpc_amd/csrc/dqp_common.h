@@ -19,6 +19,7 @@ struct KParams {
     const double *zin, *lamin, *nuin, *slackin, *gin;
     double *dQ, *dp, *dG, *dh, *dA, *db;
     int32_t *info;
+    double *workspace;            // caller-provided scratch (dqp_workspace_bytes), may be NULL
     unsigned long long *stamps;   // diagnostic: s_memtime at phase boundaries (16 per workgroup) or NULL
     int B, N, M, E;
     int ldz, ldm, lde, ldt;
@@ -34,8 +35,10 @@ struct KParams {
 extern unsigned long long *g_debug_stamps;
 int r16_forward(const KParams &P, void *stream);
 int r16_backward(const KParams &P, void *stream);
-// null-space / reduced-Hessian DPP-row kernels (dqp_r16n.hip); same return convention
+// null-space form of the forward kernel (dqp_r16n.hip); same return convention.  It parks
+// r16n_workspace_doubles(N, M, E) doubles per QP in P.workspace (0: no instantiation).
 int r16n_forward(const KParams &P, void *stream);
+long long r16n_workspace_doubles(int N, int M, int E);
 
 }  // namespace dqp
 #endif

@@ -45,4 +45,12 @@ int r16n_forward(const KParams &P, void *stream)
     return 1;
 }
 
+long long r16n_workspace_doubles(int N, int M, int E)
+{
+#define X(n, m, e) if (N == n && M == m && E == e) return (long long)e * (n - e) + (long long)e * (e - 1) / 2;
+    DQP_R16N_SIZE_LIST
+#undef X
+    return 0;
+}
+
 }  // namespace dqp

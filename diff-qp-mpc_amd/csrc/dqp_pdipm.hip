@@ -671,13 +671,17 @@ __attribute__((visibility("default"))) const char *dqp_error_string(int code)
     }
 }
 
-__attribute__((visibility("default"))) size_t dqp_workspace_bytes(const dqp_dims *) { return 0; }
+__attribute__((visibility("default"))) size_t dqp_workspace_bytes(const dqp_dims *d)
+{
+    if (!d || d->nbatch <= 0) return 0;
+    return (size_t)d->nbatch * (size_t)dqp::r16n_workspace_doubles(d->nz, d->nineq, d->neq) * sizeof(double);
+}
 
 __attribute__((visibility("default"))) int
 dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, const double *p,
                const double *G, const double *h, const double *A, const double *b, double *zhat,
                double *lam, double *nu, double *slack, int32_t *info, double *best_resid,
-               void * /*workspace*/, void *stream)
+               void *workspace, void *stream)
 {
     KParams P = {};
     size_t lds = 0;
@@ -685,15 +689,15 @@ dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, cons
     if (rc != DQP_OK) return rc;
     if (P.B == 0) return DQP_OK;
     if (!Q || !p || !G || !h || !zhat || !lam || !slack) return DQP_ERR_BAD_ARG;
+    P.workspace = (double *)workspace;
     if (P.E > 0 && (!A || !b || !nu)) return DQP_ERR_BAD_ARG;
     P.Q = Q; P.p = p; P.G = G; P.h = h; P.A = A; P.b = b;
     P.zhat = zhat; P.lam = lam; P.nu = nu; P.slack = slack;
     P.info = info; P.best_resid = best_resid;
     if (!(P.flags & DQP_FLAG_GENERIC_ONLY)) {
-        // DPP-row kernels for the instantiated sizes.  The reduced-Hessian variant is ~2x
-        // faster per iteration but, like every normal-equations IPM, recovers dz = -z - d ds by
-        // cancellation and stalls near 1e-5 on zhat: opt-in only, never the parity path.
-        rc = (P.flags & DQP_FLAG_REDUCED_HESSIAN) ? r16n_forward(P, stream) : 1;
+        // DPP-row kernels for the instantiated sizes: the null-space form when the caller gave
+        // it its workspace (and did not opt out), else the form that keeps the equality rows.
+        rc = (workspace && !(P.flags & DQP_FLAG_NO_NULLSPACE)) ? r16n_forward(P, stream) : 1;
         if (rc == 1) rc = r16_forward(P, stream);
         if (rc != 1) return rc;
     }

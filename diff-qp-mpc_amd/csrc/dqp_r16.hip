@@ -212,39 +212,6 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     STAMP(P, 5);
 }
 
-// T = R + diag(dinv) (full square, row-distributed) from the packed triangle in LDS, then LU.
-// Each lane first rewrites its own diagonal entries of the LDS triangle with R_ii + dinv_i (only
-// the owning lane ever reads them back), so the load needs no per-element diagonal select.
-template <class C>
-__device__ __forceinline__ void factor_T(double *lds, double (&T)[C::SM][C::M],
-                                         const double (&rdiag)[C::SM], const double (&dinv)[C::SM],
-                                         double (&rdu)[C::SM], int r)
-{
-    constexpr int M = C::M, SM = C::SM;
-    double *Rp = lds + C::oR;
-#pragma unroll
-    for (int s = 0; s < SM; ++s) {
-        const int i = r + 16 * s;
-        double *dst = i < M ? Rp + tri(i) + i : lds + C::oDummy + r;
-        *dst = rdiag[s] + dinv[s];
-    }
-#pragma unroll
-    for (int s = 0; s < SM; ++s) {
-        const int i = r + 16 * s;
-        const int ic = i < M ? i : M - 1;
-#pragma unroll
-        for (int j = 0; j < M; ++j) {
-            int off;
-            if (16 * s > j) off = tri(ic) + j;                          // all rows below column j
-            else if (16 * s + 15 < j) off = tri(j) + ic;                // all rows above
-            else off = (j <= ic) ? tri(ic) + j : tri(j) + ic;
-            const double v = Rp[off];
-            T[s][j] = (16 * s + 15 >= M) ? mask_hi(v, i < M) : v;       // pad rows: ~zero rows
-        }
-    }
-    lu_rows<SM, M>(T, rdu, r);
-}
-
 // Right-hand side of the z-part of solve_kkt in hat coordinates (see dqp_pdipm.hip kkt_wz):
 //   g = rz - rs/d - Gh (rxh - At^T (At rxh - ryt)).   Touches Gh/At only (not T).
 template <class C>

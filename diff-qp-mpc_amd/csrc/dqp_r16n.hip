@@ -1,15 +1,20 @@
-// dqp_r16n.hip -- DPP-row kernels, null-space / reduced-Hessian form (4 QPs per wavefront).
+// dqp_r16n.hip -- DPP-row forward kernel, null-space form (4 QPs per wavefront).
 //
 // Same layout idea as dqp_r16.hip (one QP per 16-lane DPP row, matrices row-distributed in
 // registers, v_mov_b64_dpp row_newbcast as the only cross-lane primitive) but the equality
-// constraints are eliminated ONCE, so the per-iteration linear algebra shrinks from the
-// nineq x nineq Schur complement T = R + D^-1 to the (nz-neq) x (nz-neq) reduced Hessian:
+// constraints are eliminated ONCE in setup, so the PDIPM iteration carries no equality rows:
 //
 //   hat coordinates   xh = Lq^T x (Q = Lq Lq^T),  Gh = G Lq^-T,  Ah = A Lq^-T
 //   reverse LQ        Ah Qf = [0 | U]   (Householder reflectors H_k, Qf = H_{E-1} ... H_0,
 //                                        U upper triangular E x E in the LAST E columns)
 //   null-space split  xh = Qf [w ; xy],  xy = U^-1 b fixed,  Gh Qf = [Gz | W],  h' = h - W xy
-//   reduced QP        min 1/2 |w|^2 + cp^T w   s.t.  Gz w + s = h',  s >= 0
+//   reduced QP        min 1/2 |w|^2 + cp^T w   s.t.  Gz w + s = h',  s >= 0        (R = nz - neq)
+//
+// and the iteration is the one of dqp_r16.hip with no equality block: the nineq x nineq Schur
+// complement T = Gz Gz^T + diag(s/z) is factored per iteration (the well-conditioned form: the
+// reduced-Hessian alternative I + Gz^T D Gz was tried and loses ~1e-5 to cancellation), with
+// three 30 x 15 mat-vecs instead of three 30 x 30 and five 15 x 30 ones, and the equality
+// rows gone from the register file.
 //
 // The PDIPM iterates (x, s, z) of the reference (batch.py:46-208) are reproduced exactly in
 // exact arithmetic: Newton's method is affine invariant and, with A x = b holding from the
@@ -17,16 +22,14 @@
 // The y iterate only enters the reference's stopping/selection residual through the range
 // part of rx, which obeys rho_{k+1} = (1 - alpha_k) rho_k; we carry that scalar c_k and
 // reconstruct  ||rx|| = ||(Lq Z) rw + c_k (Lq Y) rho_0||  and  y = U^-T (c rho_0 - xy - py - W^T z).
-// Per iteration:  H = I + Gz^T diag(z/s) Gz  (R x R, R = nz - neq), one unpivoted LU, two
-// solves (affine + corrector), five small mat-vecs.
 //
-// Reference functions covered: a2-a8, a9-a10 of SURVEY.md §8 (as dqp_pdipm.hip / dqp_r16.hip).
+// LDS per QP: packed Lq, then a region that holds the reflector tails during setup and the
+// epilogue and the packed Gz Gz^T during the iteration (the tails wait in the caller's
+// workspace, dqp_workspace_bytes), then the parked vectors.
+//
+// Reference functions covered: a2-a7 of SURVEY.md §8 (as dqp_pdipm.hip / dqp_r16.hip).
 
 #include "dqp_r16_prims.h"
-
-#ifndef DQP_R16N_NREF
-#define DQP_R16N_NREF 1   /* iterative-refinement steps per reduced-Hessian solve */
-#endif
 
 namespace dqp {
 namespace r16n {
@@ -40,14 +43,15 @@ template <int N_, int M_, int E_> struct Cfg {
     // LDS per QP (doubles)
     static constexpr int tailsz = E_ * (N_ - E_) + E_ * (E_ - 1) / 2;     // sum_k c_k, c_k = R + k
     static constexpr int oLq = 0;                       // packed lower triangle of Lq
-    static constexpr int oTl = tri(N_);                 // packed reflector tails u'_k[0..c_k)
-    static constexpr int oCp = oTl + tailsz;            // cp (R)
+    static constexpr int oTl = tri(N_);                 // packed reflector tails u'_k[0..c_k) ...
+    static constexpr int oR = oTl;                      // ... / packed Gz Gz^T while iterating
+    static constexpr int shared = tailsz > tri(M_) ? tailsz : tri(M_);
+    static constexpr int oCp = oTl + shared;            // cp (R)
     static constexpr int oHp = oCp + (N_ - E_);         // h' (M)
     static constexpr int oQv = oHp + M_;                // qv = Lq Y (W^T 1)  (N)
     static constexpr int oBw = oQv + N_;                // best w (R), s (M), z (M), c (1)
     static constexpr int oBs = oBw + (N_ - E_), oBz = oBs + M_, oBc = oBz + M_;
-    static constexpr int oScr = oBc + 2;                // 16 x R transpose scratch
-    static constexpr int oDummy = oScr + 16 * (N_ - E_);
+    static constexpr int oDummy = oBc + 2;              // 16 write-only sink slots
     static constexpr int ldsQP = oDummy + 16;
     static constexpr int ldsQPpad = (ldsQP + 1) & ~1;
     __host__ __device__ static constexpr int toff(int k) { return k * (N_ - E_) + k * (k - 1) / 2; }
@@ -55,7 +59,6 @@ template <int N_, int M_, int E_> struct Cfg {
 
 template <class C> struct State {
     double Gh[C::SM][C::N];     // Gh Qf = [Gz | W], row-distributed by constraint
-    double GzT[C::SR][C::M];    // Gz^T, row-distributed by reduced index
     double LqZ[C::SN][C::R];    // (Lq Qf)[:, :R]
     double Ah[C::SE][C::N];     // U = Ah[:, R:]  (columns < c_k of row k are dead)
     double tau[C::SE];          // tau'_k, E-space distributed
@@ -64,6 +67,7 @@ template <class C> struct State {
     double py[C::SE];           // (Qf^T ph)[R:]  in E-space
     double w1[C::SE];           // W^T 1
     double rdq[C::SN];
+    double rdiag[C::SM];        // diag(Gz Gz^T) of the lane's rows (factor_T rewrites the LDS copy)
     int status;
 };
 
@@ -160,17 +164,26 @@ __device__ __forceinline__ void mul_Gz(const State<C> &st, const double (&v)[C::
         for (int s = 0; s < C::SM; ++s) y[s] = fma(st.Gh[s][t], vb, y[s]);
     }
 }
-// y = Gz^T v (v in M-space) -> R-space
+// y = Gz^T v (v in M-space) -> R-space   (transposed product: partials + reduce-scatter)
 template <class C>
-__device__ __forceinline__ void mul_GzT(const State<C> &st, const double (&v)[C::SM], double (&y)[C::SR])
+__device__ __forceinline__ void mul_GzT(const State<C> &st, const double (&v)[C::SM], double (&y)[C::SR], int r)
 {
 #pragma unroll
-    for (int s = 0; s < C::SR; ++s) y[s] = 0.0;
+    for (int g = 0; g < C::SR; ++g) {
+        double p[16];
 #pragma unroll
-    for (int k = 0; k < C::M; ++k) {
-        const double vb = BC(v, k);
+        for (int k = 0; k < 16; ++k) {
+            const int c = 16 * g + k;
+            if (c < C::R) {
+                double a = st.Gh[0][c < C::R ? c : 0] * v[0];
 #pragma unroll
-        for (int s = 0; s < C::SR; ++s) y[s] = fma(st.GzT[s][k], vb, y[s]);
+                for (int s = 1; s < C::SM; ++s) a = fma(st.Gh[s][c < C::R ? c : 0], v[s], a);
+                p[k] = a;
+            } else {
+                p[k] = 0.0;
+            }
+        }
+        y[g] = reduce_scatter16(p, r);
     }
 }
 // y = W^T v (v in M-space) -> E-space   (transposed product: partials + reduce-scatter)
@@ -196,66 +209,8 @@ __device__ __forceinline__ void mul_WT(const State<C> &st, const double (&v)[C::
     }
 }
 
-// H = I + Gz^T diag(d) Gz (R x R, row-distributed in R-space), then unpivoted LU.
-template <class C>
-__device__ __forceinline__ void factor_H(const State<C> &st, const double (&d)[C::SM],
-                                         double (&H)[C::SR][C::R], double (&rdu)[C::SR], int r)
-{
-    constexpr int R = C::R, M = C::M, SR = C::SR;
-#pragma unroll
-    for (int s = 0; s < SR; ++s)
-#pragma unroll
-        for (int j = 0; j < R; ++j) H[s][j] = (r + 16 * s == j) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < M; ++k) {
-        const double dk = BC(d, k);
-        double a[SR];
-#pragma unroll
-        for (int s = 0; s < SR; ++s) a[s] = st.GzT[s][k] * dk;
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const double gb = rb(st.GzT[j >> 4][k], j & 15);
-#pragma unroll
-            for (int s = 0; s < SR; ++s) H[s][j] = fma(a[s], gb, H[s][j]);
-        }
-    }
-    // padding rows (index >= R) stay zero except nothing: give them a unit diagonal is not
-    // needed because lu_rows only pivots on k < R.
-    lu_rows<SR, R>(H, rdu, r);
-}
-
-// x <- H^-1 rhs with NREF steps of iterative refinement against the matrix-free operator
-// H x = x + Gz^T (d .* (Gz x)); the LU of the explicitly formed H has a backward error of
-// eps * ||H|| ~ eps * max(d), which refinement removes from the well-conditioned directions.
-template <class C, int NREF>
-__device__ __forceinline__ void solve_H(const State<C> &st, const double (&H)[C::SR][C::R],
-                                        const double (&rdu)[C::SR], const double (&d)[C::SM],
-                                        const double (&rhs)[C::SR], double (&x)[C::SR],
-                                        double (&gx)[C::SM], int r)
-{
-#pragma unroll
-    for (int s = 0; s < C::SR; ++s) x[s] = rhs[s];
-    lu_solve<C::SR, C::R>(H, rdu, x, r);
-    mul_Gz<C>(st, x, gx);
-#pragma unroll
-    for (int it = 0; it < NREF; ++it) {
-        double t[C::SM], res[C::SR];
-#pragma unroll
-        for (int s = 0; s < C::SM; ++s) t[s] = d[s] * gx[s];
-        mul_GzT<C>(st, t, res);
-#pragma unroll
-        for (int s = 0; s < C::SR; ++s) res[s] = (r + 16 * s < C::R) ? rhs[s] - x[s] - res[s] : 0.0;
-        lu_solve<C::SR, C::R>(H, rdu, res, r);
-#pragma unroll
-        for (int s = 0; s < C::SR; ++s) x[s] += res[s];
-        mul_Gz<C>(st, x, gx);
-    }
-}
-
 // ------------------------------------------------------------------------------------------
-// FWD = false (backward pass): p, h, b are not available (NULL) and xy / cp / h' / LqZ / qv are
-// not needed, so those phases are compiled out.
-template <class C, bool FWD>
+template <class C>
 __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, double *lds, State<C> &st)
 {
     constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
@@ -358,7 +313,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         __builtin_amdgcn_sched_barrier(0);
 
         // D: xy = U^-1 b
-        if (FWD) {
+        {
             double b[SE];
 #pragma unroll
             for (int s = 0; s < SE; ++s) b[s] = (r + 16 * s < E) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
@@ -379,7 +334,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    if (FWD) {   // E: ph = Lq^-1 p ; [cp ; py] = Qf^T ph
+    {   // E: ph = Lq^-1 p ; [cp ; py] = Qf^T ph
         double ph[SN];
 #pragma unroll
         for (int s = 0; s < SN; ++s) ph[s] = (r + 16 * s < N) ? P.p[qp * P.sp + r + 16 * s] : 0.0;
@@ -396,7 +351,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
             *dst = ph[s];
         }
     }
-    if (FWD) {   // F: h' = h - W xy ;  w1 = W^T 1
+    {   // F: h' = h - W xy ;  w1 = W^T 1
         double hp[SM];
 #pragma unroll
         for (int s = 0; s < SM; ++s) hp[s] = (r + 16 * s < M) ? P.h[qp * P.sh + r + 16 * s] : 0.0;
@@ -416,7 +371,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    if (FWD) {   // G: LqZ = (Lq Qf)[:, :R] ;  qv = (Lq Qf)[:, R:] w1
+    {   // G: LqZ = (Lq Qf)[:, :R] ;  qv = (Lq Qf)[:, R:] w1
         double Ld[SN][N];
         const double *Lp = lds + C::oLq;
 #pragma unroll
@@ -473,36 +428,45 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // H: GzT via a two-pass LDS transpose (16 constraint rows at a time)
+    // H: the reflector tails are done for now: park them in the caller's workspace (read back
+    // for the epilogue), then Rm = Gz Gz^T goes, packed, into the same LDS region.
+    if (E > 0) {
+        double *ws = P.workspace + qp * (long long)C::tailsz;
+        for (int e = r; e < C::tailsz; e += 16) ws[e] = lds[C::oTl + e];
+    }
+    __syncthreads();
     {
-        double *scr = lds + C::oScr;
+        double *Rp = lds + C::oR;
 #pragma unroll
-        for (int s = 0; s < SM; ++s) {
-            __syncthreads();
+        for (int j = 0; j < M; ++j) {
+            const int sj = j >> 4, lj = j & 15;
+            double acc[SM];
 #pragma unroll
-            for (int t = 0; t < R; ++t) scr[r * R + t] = st.Gh[s][t];
-            __syncthreads();
+            for (int s = 0; s < SM; ++s) acc[s] = 0.0;
 #pragma unroll
-            for (int sr = 0; sr < SR; ++sr) {
-                const int t = r + 16 * sr, tc = t < R ? t : R - 1;
+            for (int c = 0; c < R; ++c) {
+                const double gb = rb(st.Gh[sj][c], lj);
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    const int k = 16 * s + kk;
-                    if (k < M) {
-                        const double v = scr[kk * R + tc];
-                        st.GzT[sr][k < M ? k : 0] = (t < R) ? v : 0.0;
-                    }
-                }
+                for (int s = 0; s < SM; ++s)
+                    if (16 * s + 15 >= j) acc[s] = fma(st.Gh[s][c], gb, acc[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < SM; ++s) {
+                if (16 * s + 15 < j) continue;
+                const int i = r + 16 * s;
+                double *dst = (i < M && j <= i) ? Rp + tri(i) + j : dummy;
+                *dst = acc[s];
             }
         }
     }
-    __syncthreads();
+    __syncthreads();   // factor_T reads R[j][i] written by the lane that owns row j
+#pragma unroll
+    for (int s = 0; s < SM; ++s) {
+        const int i = r + 16 * s;
+        const double v = (lds + C::oR)[tri(i < M ? i : M - 1) + (i < M ? i : M - 1)];
+        st.rdiag[s] = i < M ? v : 0.0;
+    }
     __builtin_amdgcn_sched_barrier(0);
-}
-
-__device__ __forceinline__ double ratio(double v, double dv, bool active)
-{
-    return (active && dv < 0.0) ? -v / dv : INFINITY;
 }
 
 // y = LqZ v + cc * qv   (N-space), returns sum of squares partial (lane-local)
@@ -535,12 +499,12 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
     long long qp = (long long)blockIdx.x * 4 + qrow;
     const bool live = qp < P.B;
-    if (!live) qp = P.B - 1;
+    if (!live) qp = P.B - 1;                     // duplicate the last QP; its stores are masked
     double *lds = sm + qrow * C::ldsQPpad;
     double *dummy = lds + C::oDummy + r;
 
     State<C> st;
-    setup<C, true>(P, qp, r, lds, st);
+    setup<C>(P, qp, r, lds, st);
 
     bool inM[SM], inR[SR];
 #pragma unroll
@@ -548,30 +512,34 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
 #pragma unroll
     for (int s = 0; s < SR; ++s) inR[s] = r + 16 * s < R;
 
-    double H[SR][R], rdu[SR];
-    double w[SR], s_[SM], z[SM], gw[SM];
+    double T[SM][M], rdu[SM];
+    double w[SR], s_[SM], z[SM];
     double cc = 1.0, delta = 0.0;
-    {   // initial point (batch.py:60-86):  (I + Gz^T Gz) w = Gz^T h' - cp ;  z = Gz w - h' ; s = -z
-        double one[SM], hp[SM], cp[SR], rhs[SR];
+    {   // initial point, d = 1 (batch.py:60-86):  (Gz Gz^T + I) z = -h' - Gz cp,  w = -cp - Gz^T z
+        double one[SM], hp[SM], cp[SR], g[SM], gtz[SR];
 #pragma unroll
         for (int s = 0; s < SM; ++s) one[s] = inM[s] ? 1.0 : 0.0;
-        factor_H<C>(st, one, H, rdu, r);
         vec_get<SM>(lds + C::oHp, hp, M, r);
         vec_get<SR>(lds + C::oCp, cp, R, r);
-        mul_GzT<C>(st, hp, rhs);
+        mul_Gz<C>(st, cp, g);
 #pragma unroll
-        for (int s = 0; s < SR; ++s) w[s] = inR[s] ? rhs[s] - cp[s] : 0.0;
-        lu_solve<SR, R>(H, rdu, w, r);
-        mul_Gz<C>(st, w, gw);
+        for (int s = 0; s < SM; ++s) g[s] = inM[s] ? -hp[s] - g[s] : 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        factor_T<C>(lds, T, st.rdiag, one, rdu, r);
+        lu_solve<SM, M>(T, rdu, g, r);
+        __builtin_amdgcn_sched_barrier(0);
+        mul_GzT<C>(st, g, gtz, r);
+#pragma unroll
+        for (int s = 0; s < SR; ++s) w[s] = inR[s] ? -cp[s] - gtz[s] : 0.0;
         double ms = INFINITY, mz = INFINITY;
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
-            z[s] = inM[s] ? gw[s] - hp[s] : 0.0;
+            z[s] = inM[s] ? g[s] : 0.0;
             s_[s] = -z[s];
             ms = fmin(ms, inM[s] ? s_[s] : INFINITY);
             mz = fmin(mz, inM[s] ? z[s] : INFINITY);
         }
-        ms = row_min(ms); mz = row_min(mz);
+        ms = row_min(ms); mz = row_min(mz);                                 // batch.py:76-86
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
             if (ms < 0.0 && inM[s]) s_[s] -= ms - 1.0;
@@ -580,19 +548,23 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         delta = mz < 0.0 ? 1.0 - mz : 0.0;        // rho_0 = delta * W^T 1
     }
 
+    // gz = Gz^T z is carried incrementally (updated with the step's own transposed product)
+    double gz[SR];
+    mul_GzT<C>(st, z, gz, r);
     double best = INFINITY, bestc = 1.0;
     bool have_best = false, done = false;
     int nNot = 0, iters = 0;
 
     for (int it = 0; it < P.maxIter; ++it) {
+        // residuals                                                        batch.py:93-108
         double rw[SR], rz[SM];
         {
-            double cp[SR], hp[SM];
-            mul_GzT<C>(st, z, rw);
+            double cp[SR], hp[SM], gw[SM];
             vec_get<SR>(lds + C::oCp, cp, R, r);
             vec_get<SM>(lds + C::oHp, hp, M, r);
+            mul_Gz<C>(st, w, gw);
 #pragma unroll
-            for (int s = 0; s < SR; ++s) rw[s] = inR[s] ? rw[s] + w[s] + cp[s] : 0.0;
+            for (int s = 0; s < SR; ++s) rw[s] = inR[s] ? w[s] + cp[s] + gz[s] : 0.0;
 #pragma unroll
             for (int s = 0; s < SM; ++s) rz[s] = inM[s] ? gw[s] + s_[s] - hp[s] : 0.0;
         }
@@ -601,8 +573,9 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         for (int s = 0; s < SM; ++s) { sz = fma(s_[s], z[s], sz); nz2 = fma(rz[s], rz[s], nz2); }
         double nx2 = rx_norm2_partial<C>(st, lds, rw, cc * delta, r);
         sz = row_sum(sz); nz2 = row_sum(nz2); nx2 = row_sum(nx2);
-        const double mu = fabs(sz / M);
+        const double mu = fabs(sz * (1.0 / M));
         const double resid = sqrt(nz2) + sqrt(nx2) + M * mu;
+        // best-iterate tracking / per-problem termination (uniform inside a DPP row)
         if (!done) {
             iters = it + 1;
             if (!have_best || resid < best) {
@@ -617,73 +590,83 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
                 !(fabs(resid) < INFINITY))
                 done = true;
         }
+        // the wave leaves when all four of its QPs are done
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
 
-        double d[SM];
-#pragma unroll
-        for (int s = 0; s < SM; ++s) d[s] = inM[s] ? z[s] / s_[s] : 0.0;
-        factor_H<C>(st, d, H, rdu, r);
-
-        // affine: H dw = -rw + Gz^T (z - d rz);  ds = -rz - Gz dw;  dz = -z - d ds
-        double tmpM[SM], dwa[SR], gda[SM], dsa[SM], dza[SM];
-#pragma unroll
-        for (int s = 0; s < SM; ++s) tmpM[s] = inM[s] ? z[s] - d[s] * rz[s] : 0.0;
+        // phase 1 (Gz live, T dead): affine right-hand side  g = rz - rs/d - Gz rw,  rs/d = s
+        double dza[SM], dsa[SM];
         {
-            double rhs[SR];
-            mul_GzT<C>(st, tmpM, rhs);
+            double gu[SM];
+            mul_Gz<C>(st, rw, gu);
 #pragma unroll
-            for (int s = 0; s < SR; ++s) rhs[s] = inR[s] ? rhs[s] - rw[s] : 0.0;
-            solve_H<C, DQP_R16N_NREF>(st, H, rdu, d, rhs, dwa, gda, r);
+            for (int s = 0; s < SM; ++s) dza[s] = rz[s] - s_[s] - gu[s];
         }
-        double am = INFINITY;
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2 (T live): factor + affine and corrector solves              batch.py:110-181
+        double dinv[SM];
+#pragma unroll
+        for (int s = 0; s < SM; ++s) dinv[s] = inM[s] ? s_[s] * frcp(z[s]) : 0.0;   // 1/d, d = z/s
+        factor_T<C>(lds, T, st.rdiag, dinv, rdu, r);
+        lu_solve<SM, M>(T, rdu, dza, r);
+        double rzv[SM], rsv[SM];           // formed only now: not live across the factorisation
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
-            dsa[s] = inM[s] ? -rz[s] - gda[s] : 0.0;
-            dza[s] = inM[s] ? -z[s] - d[s] * dsa[s] : 0.0;
-            am = fmin(am, fmin(ratio(z[s], dza[s], inM[s]), ratio(s_[s], dsa[s], inM[s])));
+            rzv[s] = inM[s] ? frcp(z[s]) : 0.0;
+            rsv[s] = inM[s] ? frcp(s_[s]) : 0.0;
         }
-        double alpha = fmin(row_min(am), 1.0);
+        double tm = 0.0;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            dsa[s] = (-z[s] - dza[s]) * dinv[s];
+            tm = fmax(tm, fmax(-dza[s] * rzv[s], -dsa[s] * rsv[s]));
+        }
+        double alpha = frcp(fmax(row_max(tm), 1.0));                           // min(step, 1)
         double t3 = 0.0;
 #pragma unroll
         for (int s = 0; s < SM; ++s)
-            t3 += inM[s] ? (s_[s] + alpha * dsa[s]) * (z[s] + alpha * dza[s]) : 0.0;
+            t3 = fma(fma(alpha, dsa[s], s_[s]), fma(alpha, dza[s], z[s]), t3);
         t3 = row_sum(t3);
         double sig = t3 / sz;
         sig = sig * sig * sig;
-        // corrector: rs = (-mu sig + ds_a dz_a)/s, rw = rz = 0
-        double rsc[SM], dwc[SR], gdc[SM];
-#pragma unroll
-        for (int s = 0; s < SM; ++s) rsc[s] = inM[s] ? (-mu * sig + dsa[s] * dza[s]) / s_[s] : 0.0;
-        {
-            double rhs[SR];
-            mul_GzT<C>(st, rsc, rhs);
-#pragma unroll
-            for (int s = 0; s < SR; ++s) rhs[s] = inR[s] ? rhs[s] : 0.0;
-            solve_H<C, DQP_R16N_NREF>(st, H, rdu, d, rhs, dwc, gdc, r);
-        }
-        double ds[SM], dz[SM];
-        am = INFINITY;
+        // corrector: rw = rz = 0, rs = (-mu sig + ds_a dz_a)/s                batch.py:171-181
+        double rsc[SM], dzc[SM], dz[SM], ds[SM];
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
-            const double dsc = inM[s] ? -gdc[s] : 0.0;
-            const double dzc = inM[s] ? -rsc[s] - d[s] * dsc : 0.0;
-            ds[s] = dsa[s] + dsc;
-            dz[s] = dza[s] + dzc;
-            am = fmin(am, fmin(ratio(z[s], dz[s], inM[s]), ratio(s_[s], ds[s], inM[s])));
+            rsc[s] = fma(dsa[s], dza[s], -mu * sig) * rsv[s];
+            dzc[s] = -rsc[s] * dinv[s];
         }
-        alpha = fmin(0.999 * row_min(am), 1.0);
+        lu_solve<SM, M>(T, rdu, dzc, r);
+        tm = 0.0;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            dz[s] = dza[s] + dzc[s];
+            ds[s] = fma(-rsc[s] - dzc[s], dinv[s], dsa[s]);
+            tm = fmax(tm, fmax(-dz[s] * rzv[s], -ds[s] * rsv[s]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 3 (Gz live, T dead): dw = -rw - Gz^T dz
+        double gtd[SR];
+        mul_GzT<C>(st, dz, gtd, r);
+        alpha = frcp(fmax(row_max(tm) * (1.0 / 0.999), 1.0));                  // min(0.999 step, 1)
         if (!done) {
 #pragma unroll
-            for (int s = 0; s < SR; ++s) w[s] = fma(alpha, dwa[s] + dwc[s], w[s]);
-#pragma unroll
-            for (int s = 0; s < SM; ++s) {
-                gw[s] = fma(alpha, gda[s] + gdc[s], gw[s]);
-                s_[s] = fma(alpha, ds[s], s_[s]);
-                z[s] = fma(alpha, dz[s], z[s]);
+            for (int s = 0; s < SR; ++s) {
+                w[s] = fma(alpha, -rw[s] - gtd[s], w[s]);
+                gz[s] = fma(alpha, gtd[s], gz[s]);
             }
+#pragma unroll
+            for (int s = 0; s < SM; ++s) { s_[s] = fma(alpha, ds[s], s_[s]); z[s] = fma(alpha, dz[s], z[s]); }
             cc *= (1.0 - alpha);
         }
     }
+
+    // the reflector tails come back from the workspace into the (now idle) Gz Gz^T region
+    __syncthreads();
+    if (E > 0) {
+        const double *ws = P.workspace + qp * (long long)C::tailsz;
+        for (int e = r; e < C::tailsz; e += 16) lds[C::oTl + e] = ws[e];
+    }
+    __syncthreads();
 
     // recover x = Lq^-T Qf [w* ; xy],  y = U^-T (c* delta w1 - xy - py - W^T z*)
     double bw[SR], bs[SM], bz[SM];

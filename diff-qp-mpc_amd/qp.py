@@ -94,11 +94,13 @@ def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim):
     nu = torch.empty(nBatch, neq, **kw)
     info = torch.empty(nBatch, 2, dtype=torch.int32, device=dev)
     resid = torch.empty(nBatch, **kw)
+    # scratch for the null-space forward kernels (include/dqp.h: dqp_workspace_bytes)
+    wsb = int(lib.dqp_workspace_bytes(ctypes.byref(dims)))
+    ws = torch.empty(wsb // 8, **kw) if wsb > 0 else None
     with torch.cuda.device(dev):
         rc = lib.dqp_qp_forward(ctypes.byref(dims), ctypes.byref(opts), _ptr(Q), _ptr(p), _ptr(G),
                                 _ptr(h), _ptr(A), _ptr(b), _ptr(zhat), _ptr(lam), _ptr(nu),
-                                _ptr(slack), _ptr(info), _ptr(resid), ctypes.c_void_p(0),
-                                _stream(dev))
+                                _ptr(slack), _ptr(info), _ptr(resid), _ptr(ws), _stream(dev))
     _lib.check(rc, "dqp_qp_forward")
     return zhat, lam, nu, slack, info, resid, (Q, G, A, dims)
 

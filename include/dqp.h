@@ -52,8 +52,8 @@ enum {
                                       without the 1e-8 clamps of QPFunction (qp.py:149)   */
 
 #define DQP_FLAG_GENERIC_ONLY 2u   /* testing: skip the size-specialised DPP-row kernels     */
-#define DQP_FLAG_REDUCED_HESSIAN 4u /* opt-in fast forward (null-space / reduced Hessian): zhat
-                                      accurate to ~1e-5 only; not the parity path            */
+#define DQP_FLAG_NO_NULLSPACE 4u   /* forward: keep the equality rows in the iteration even when a
+                                      workspace is given (the kernel used without one)       */
 
 typedef struct dqp_dims {
     int32_t nbatch;
@@ -76,8 +76,12 @@ typedef struct dqp_opts {
 int dqp_version(void);
 const char *dqp_error_string(int code);
 
-/* Bytes of caller-provided device workspace the calls below need (0 in this build: all
- * solver state lives in LDS/registers). */
+/* Bytes of caller-provided device workspace for dqp_qp_forward (8-byte aligned; contents are
+ * scratch).  Optional: with workspace == NULL, or a size for which this returns 0, every
+ * solver state lives in LDS/registers.  With it, the size-specialised forward kernels
+ * eliminate the equality constraints once (null-space form) and park the elimination's
+ * reflectors there between setup and the final back-transformation -- ~1.4x faster at the
+ * metric size, same iterates in exact arithmetic.  dqp_qp_backward needs none. */
 size_t dqp_workspace_bytes(const dqp_dims *dims);
 
 /*

@@ -29,12 +29,15 @@ DT = dict(rtol=1e-5, atol=1e-7)
 GT = dict(rtol=1e-4, atol=1e-6)
 
 
-@pytest.fixture(params=["auto", "generic"], autouse=True)
+@pytest.fixture(params=["auto", "rows", "generic"], autouse=True)
 def kernel_family(request):
-    """Every test runs against both kernel families: automatic dispatch (DPP-row kernels where
-    instantiated) and the generic one-QP-per-wavefront LDS kernels."""
+    """Every test runs against all three kernel families: automatic dispatch (DPP-row kernels
+    where instantiated, null-space forward), the DPP-row forward that keeps the equality rows
+    (what runs when the caller passes no workspace), and the generic one-QP-per-wavefront LDS
+    kernels."""
     from diff_qp_mpc_amd import qp as qpmod, _lib
-    qpmod.FORCE_FLAGS = {"auto": 0, "generic": _lib.DQP_FLAG_GENERIC_ONLY}[request.param]
+    qpmod.FORCE_FLAGS = {"auto": 0, "rows": _lib.DQP_FLAG_NO_NULLSPACE,
+                         "generic": _lib.DQP_FLAG_GENERIC_ONLY}[request.param]
     yield request.param
     qpmod.FORCE_FLAGS = 0
 
@@ -233,18 +236,37 @@ def test_shared_parameters_at_dpp_row_size(dqp):
         np.testing.assert_allclose(t.grad.cpu().numpy(), want, err_msg="d" + k, **GT)
 
 
-def test_reduced_hessian_fast_mode(dqp):
-    """Opt-in DQP_FLAG_REDUCED_HESSIAN forward: same optimum to the looser 1e-4 it promises."""
-    from diff_qp_mpc_amd import qp as qpmod, _lib
+def test_workspace_is_optional(dqp):
+    """dqp_qp_forward without a workspace (NULL) runs the equality-row kernels and gives the same
+    answer as the null-space path that uses it; dqp_workspace_bytes is what include/dqp.h says."""
+    import ctypes
+    from diff_qp_mpc_amd import _lib
+    lib = _lib.load()
     g = load("R_metric_b8")
-    ins = [dev(g["in_" + k], grad=False) for k in "QpGhAb"]
-    qpmod.FORCE_FLAGS = _lib.DQP_FLAG_REDUCED_HESSIAN
-    try:
-        zhat, lam, nu, slack, info, resid, _ = qpmod._forward_impl(*ins, 1e-12, 20, 3)
-    finally:
-        qpmod.FORCE_FLAGS = 0
-    np.testing.assert_allclose(zhat.cpu().numpy(), g["zhat"], rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(nu.cpu().numpy(), g["nu"], rtol=1e-3, atol=1e-3)
+    Q, p, G, h, A, b = [dev(g["in_" + k], grad=False) for k in "QpGhAb"]
+    B, nz, nineq, neq = 8, 30, 30, 15
+    dims = _lib.dqp_dims(B, nz, nineq, neq, nz * nz, nz, nineq * nz, nineq, neq * nz, neq)
+    assert lib.dqp_workspace_bytes(ctypes.byref(dims)) == B * (15 * 15 + 15 * 14 // 2) * 8
+    odd = _lib.dqp_dims(B, 7, 5, 2, 49, 7, 35, 5, 14, 2)
+    assert lib.dqp_workspace_bytes(ctypes.byref(odd)) == 0         # generic kernels: no scratch
+    opts = _lib.dqp_opts(1e-12, 1e-10, 20, 3, 0, 0)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    outs = []
+    for use_ws in (False, True):
+        kw = dict(dtype=torch.float64, device="cuda")
+        zhat, lam, nu, slack = (torch.empty(B, n, **kw) for n in (nz, nineq, neq, nineq))
+        info = torch.empty(B, 2, dtype=torch.int32, device="cuda")
+        ws = torch.empty(B * 330, **kw)
+        rc = lib.dqp_qp_forward(ctypes.byref(dims), ctypes.byref(opts), P(Q), P(p), P(G), P(h), P(A),
+                                P(b), P(zhat), P(lam), P(nu), P(slack), P(info), None,
+                                P(ws) if use_ws else None, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        outs.append([t.cpu().numpy() for t in (zhat, lam, nu, slack)])
+        np.testing.assert_allclose(outs[-1][0], g["zhat"], **ZT)
+        np.testing.assert_allclose(outs[-1][2], g["nu"], **DT)
+    for a0, a1 in zip(*outs):
+        np.testing.assert_allclose(a0, a1, rtol=1e-6, atol=1e-8)
 
 
 def test_not_spd_raises(dqp):
