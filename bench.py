@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # public MI355X spec (vector = matrix fp64); not in the guide
 # ~50 kFLOP per PDIPM iteration + 0.27 MFLOP one-time factorisations per QP
 FLOP_SETUP, FLOP_PER_ITER = 0.27e6, 50e3
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "v3_r16_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "v5_nullspace_pmc_summary.json")
 
 
 def measured_traffic(kernel_key):
@@ -225,7 +225,7 @@ def main():
                                    "BASELINE metric batch: B=4096/GPU nz=30 nineq=30 neq=15",
                        "global_batch": world * B_PER_GPU, "n_state": 3, "n_ctrl": 3, "T": 5,
                        "parallelism": "batch-shard x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "dqp::r16::forward_kernel<Cfg<30,30,15>>",
+            "roofline": {"bound": "hbm", "kernel": "dqp::r16n::forward_kernel<Cfg<30,30,15>>",
                          "achieved": fwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": fwd_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("forward"),
                          "avg_launch_ms": fwd_ms, "algorithmic_bytes_per_launch": fwd_bytes,
