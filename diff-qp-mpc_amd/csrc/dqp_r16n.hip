@@ -217,6 +217,15 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     constexpr int SN = C::SN, SM = C::SM, SE = C::SE, SR = C::SR;
     double *dummy = lds + C::oDummy + r;
     st.status = DQP_STATUS_OK;
+    // the three right-hand-side vectors are fetched now and consumed in phases D-F, so their HBM
+    // latency hides under the factorisations instead of serialising three more round trips
+    double p0[SN], h0[SM], b0[SE];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) p0[s] = (r + 16 * s < N) ? P.p[qp * P.sp + r + 16 * s] : 0.0;
+#pragma unroll
+    for (int s = 0; s < SM; ++s) h0[s] = (r + 16 * s < M) ? P.h[qp * P.sh + r + 16 * s] : 0.0;
+#pragma unroll
+    for (int s = 0; s < SE; ++s) b0[s] = (E > 0 && r + 16 * s < E) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
     {   // A: Q -> Lq -> packed LDS
         double Lq[SN][N];
         load_rows<SN, N>(P.Q + qp * P.sQ, N, Lq, r);
@@ -316,7 +325,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         {
             double b[SE];
 #pragma unroll
-            for (int s = 0; s < SE; ++s) b[s] = (r + 16 * s < E) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
+            for (int s = 0; s < SE; ++s) b[s] = b0[s];
 #pragma unroll
             for (int j = E - 1; j >= 0; --j) {
                 const int sj = j >> 4, lj = j & 15;
@@ -337,7 +346,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     {   // E: ph = Lq^-1 p ; [cp ; py] = Qf^T ph
         double ph[SN];
 #pragma unroll
-        for (int s = 0; s < SN; ++s) ph[s] = (r + 16 * s < N) ? P.p[qp * P.sp + r + 16 * s] : 0.0;
+        for (int s = 0; s < SN; ++s) ph[s] = p0[s];
         tri_solve<SN, N>(lds + C::oLq, st.rdq, ph, r);
         if (E > 0) {
             apply_QfT<C>(lds, st.tau, ph, r);
@@ -354,7 +363,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     {   // F: h' = h - W xy ;  w1 = W^T 1
         double hp[SM];
 #pragma unroll
-        for (int s = 0; s < SM; ++s) hp[s] = (r + 16 * s < M) ? P.h[qp * P.sh + r + 16 * s] : 0.0;
+        for (int s = 0; s < SM; ++s) hp[s] = h0[s];
         if (E > 0) {
 #pragma unroll
             for (int e = 0; e < E; ++e) {
