@@ -22,4 +22,4 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recurs
         res[k]["trace_avg_us"] = float(row["AverageNs"]) / 1e3
         res[k]["trace_min_us"] = float(row["MinNs"]) / 1e3
         res[k]["trace_max_us"] = float(row["MaxNs"]) / 1e3
-print(json.dumps({k: v for k, v in res.items() if "dqp" in k or "al_" in k}, indent=1, sort_keys=True))
+print(json.dumps({k: v for k, v in res.items() if "dqp" in k or "al_newton" in k or "al_chol" in k}, indent=1, sort_keys=True))
