@@ -6,7 +6,7 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 out = sys.argv[1]
-short = lambda n: re.sub(r"\(.*$", "", n).replace("void ", "").strip()
+short = lambda n: re.sub(r"\(.*$", "", n.replace("(anonymous namespace)::", "")).replace("void ", "").strip()
 res = defaultdict(dict)
 for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
     per = defaultdict(lambda: defaultdict(float))       # (kernel, counter) -> dispatch -> value
