@@ -726,9 +726,10 @@ dqp_qp_backward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, con
     P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db;
     P.info = info;
     if (!(P.flags & DQP_FLAG_GENERIC_ONLY)) {
-        // Backward is ONE solve: the Schur-complement form (T = R + D^-1) keeps
-        // dlam accurate for strongly active constraints (d ~ 1e8 after the reference's clamps),
-        // where the reduced-Hessian form loses ~1e-6 to cancellation, so it is used here.
+        // Backward is ONE solve, always in the Schur-complement form (T = R + D^-1 keeps dlam
+        // accurate for strongly active constraints, d ~ 1e8 after the reference's clamps).  A
+        // null-space backward (dqp_r16n.hip: backward_kernel, -DDQP_R16_BWD) exists and is parity
+        // green, but its setup spills under this compiler (0.30 ms vs 0.07 ms), so it is not built.
         rc = r16_backward(P, stream);
         if (rc != 1) return rc;
     }

@@ -56,6 +56,11 @@ __device__ __forceinline__ double row_max(double v)
     return v;
 }
 
+// Pins a value's definition where it is written: without it the compiler may sink a per-step
+// `if (r == k) rd = x` select to the first use of rd, keeping all N candidates x alive (60 VGPRs
+// through the next phase) -- seen in the null-space backward kernel: 5.7 KB/lane of spills.
+#define PIN(x) asm volatile("" : "+v"(x))
+
 // keep ? v : (v with its high word cleared).  The cleared value is 0 or a positive denormal
 // below 2^-1042, which every FMA on normal-range data absorbs exactly -- one v_cndmask instead of
 // the two a full 64-bit select costs (these kernels issue one instruction per 4 cycles, so
@@ -189,6 +194,7 @@ __device__ __forceinline__ bool chol_rows(double (&L)[S][N], double (&rd)[S], in
         if (!(dk > 0.0)) { ok = false; dk = 1.0; }
         const double ri = frsqrt(dk);
         if (r == lk) rd[sk] = ri;
+        PIN(rd[sk]);
         double col[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -220,6 +226,7 @@ __device__ __forceinline__ void lu_rows(double (&T)[S][N], double (&rdu)[S], int
         const int sk = k >> 4, lk = k & 15;
         const double rp = frcp(rb(T[sk][k], lk));
         if (r == lk) rdu[sk] = rp;
+        PIN(rdu[sk]);
         double l[S];
 #pragma unroll
         for (int s = 0; s < S; ++s) {

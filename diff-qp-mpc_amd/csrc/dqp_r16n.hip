@@ -210,7 +210,9 @@ __device__ __forceinline__ void mul_WT(const State<C> &st, const double (&v)[C::
 }
 
 // ------------------------------------------------------------------------------------------
-template <class C>
+// FWD = false (backward pass): only the factorisations A-C run (p, h, b are not given and the
+// reduced cost vector / h' / Lq Z / Gz Gz^T are not needed).
+template <class C, bool FWD>
 __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, double *lds, State<C> &st)
 {
     constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
@@ -221,11 +223,11 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     // latency hides under the factorisations instead of serialising three more round trips
     double p0[SN], h0[SM], b0[SE];
 #pragma unroll
-    for (int s = 0; s < SN; ++s) p0[s] = (r + 16 * s < N) ? P.p[qp * P.sp + r + 16 * s] : 0.0;
+    for (int s = 0; s < SN; ++s) p0[s] = (FWD && r + 16 * s < N) ? P.p[qp * P.sp + r + 16 * s] : 0.0;
 #pragma unroll
-    for (int s = 0; s < SM; ++s) h0[s] = (r + 16 * s < M) ? P.h[qp * P.sh + r + 16 * s] : 0.0;
+    for (int s = 0; s < SM; ++s) h0[s] = (FWD && r + 16 * s < M) ? P.h[qp * P.sh + r + 16 * s] : 0.0;
 #pragma unroll
-    for (int s = 0; s < SE; ++s) b0[s] = (E > 0 && r + 16 * s < E) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
+    for (int s = 0; s < SE; ++s) b0[s] = (FWD && E > 0 && r + 16 * s < E) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
     {   // A: Q -> Lq -> packed LDS
         double Lq[SN][N];
         load_rows<SN, N>(P.Q + qp * P.sQ, N, Lq, r);
@@ -259,6 +261,9 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
 #pragma unroll
                 for (int s = 0; s < SE; ++s) st.Ah[s][j] *= rj;
             }
+            // keep each column's LDS reads next to their FMAs (otherwise the scheduler may drift
+            // the Ah chain away from the Gh chain and spill the Lq values in between)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -322,7 +327,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         __builtin_amdgcn_sched_barrier(0);
 
         // D: xy = U^-1 b
-        {
+        if (FWD) {
             double b[SE];
 #pragma unroll
             for (int s = 0; s < SE; ++s) b[s] = b0[s];
@@ -342,6 +347,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (!FWD) return;
 
     {   // E: ph = Lq^-1 p ; [cp ; py] = Qf^T ph
         double ph[SN];
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     double *dummy = lds + C::oDummy + r;
 
     State<C> st;
-    setup<C>(P, qp, r, lds, st);
+    setup<C, true>(P, qp, r, lds, st);
 
     bool inM[SM], inR[SR];
 #pragma unroll
@@ -718,6 +724,159 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     }
 }
 
+// Backward pass in the same null-space coordinates (reference: qp.py:128-183 = factor_kkt +
+// solve_kkt with rhs (dl_dzhat, 0, 0, 0) + the outer-product gradient formulas).  With
+// gq = Qf^T Lq^-1 g split into its null-space part gz and range part gy:
+//   (Gz Gz^T + diag(s/lam)) dlam = -Gz gz,   dw = -(gz + Gz^T dlam),   dx = Lq^-T Qf [dw ; 0],
+//   dnu = -U^-T (gy + W^T dlam).
+// Only the factorisations A-C of setup are needed, T is accumulated straight into registers
+// (no packed Gz Gz^T in LDS, so the reflectors stay resident and no workspace is used).
+template <class C>
+__global__ __launch_bounds__(64) void backward_kernel(KParams P)
+{
+    constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
+    constexpr int SN = C::SN, SM = C::SM, SE = C::SE, SR = C::SR;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
+    long long qp = (long long)blockIdx.x * 4 + qrow;
+    const bool live = qp < P.B;
+    if (!live) qp = P.B - 1;
+    double *lds = sm + qrow * C::ldsQPpad;
+
+    State<C> st;
+    setup<C, false>(P, qp, r, lds, st);
+
+    bool inN[SN], inM[SM], inE[SE];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) inN[s] = r + 16 * s < N;
+#pragma unroll
+    for (int s = 0; s < SM; ++s) inM[s] = r + 16 * s < M;
+#pragma unroll
+    for (int s = 0; s < SE; ++s) inE[s] = r + 16 * s < E;
+
+    double zh[SN], g[SN], lam[SM], dinv[SM], nu[SE];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) {
+        zh[s] = inN[s] ? P.zin[qp * N + r + 16 * s] : 0.0;
+        g[s] = inN[s] ? P.gin[qp * N + r + 16 * s] : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < SM; ++s) {
+        lam[s] = inM[s] ? P.lamin[qp * M + r + 16 * s] : 0.0;
+        const double sl = inM[s] ? P.slackin[qp * M + r + 16 * s] : 1.0;
+        if (P.flags & DQP_FLAG_DENSE_BACKWARD) dinv[s] = inM[s] ? sl / lam[s] : 0.0;
+        else dinv[s] = inM[s] ? fmax(sl, 1e-8) / fmax(lam[s], 1e-8) : 0.0;     // qp.py:149
+    }
+#pragma unroll
+    for (int s = 0; s < SE; ++s) nu[s] = (E > 0 && inE[s]) ? P.nuin[qp * E + r + 16 * s] : 0.0;
+
+    // gq = Qf^T Lq^-1 g
+    tri_solve<SN, N>(lds + C::oLq, st.rdq, g, r);
+    double gy[SE];
+#pragma unroll
+    for (int s = 0; s < SE; ++s) gy[s] = 0.0;
+    if (E > 0) {
+        apply_QfT<C>(lds, st.tau, g, r);
+        shift_down<C>(g, gy, r);
+    }
+    double gz[SR];
+#pragma unroll
+    for (int s = 0; s < SR; ++s) gz[s] = (r + 16 * s < R) ? g[s] : 0.0;
+
+    double dlam[SM];
+    mul_Gz<C>(st, gz, dlam);
+#pragma unroll
+    for (int s = 0; s < SM; ++s) dlam[s] = -dlam[s];
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        double T[SM][M], rdu[SM];
+#pragma unroll
+        for (int j = 0; j < M; ++j) {                  // column by column: short live ranges
+            const int sj = j >> 4, lj = j & 15;
+            double acc[SM];
+#pragma unroll
+            for (int s = 0; s < SM; ++s) acc[s] = (r + 16 * s == j) ? dinv[s] : 0.0;
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const double gb = rb(st.Gh[sj][c], lj);
+#pragma unroll
+                for (int s = 0; s < SM; ++s) acc[s] = fma(st.Gh[s][c], gb, acc[s]);
+            }
+#pragma unroll
+            for (int s = 0; s < SM; ++s) T[s][j] = acc[s];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        lu_rows<SM, M>(T, rdu, r);
+        lu_solve<SM, M>(T, rdu, dlam, r);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    double dxh[SN], dnu[SE];
+    {
+        double gtd[SR];
+        mul_GzT<C>(st, dlam, gtd, r);
+#pragma unroll
+        for (int s = 0; s < SN; ++s) dxh[s] = (s < SR && r + 16 * s < R) ? -(gz[s < SR ? s : 0] + gtd[s < SR ? s : 0]) : 0.0;
+    }
+#pragma unroll
+    for (int s = 0; s < SE; ++s) dnu[s] = 0.0;
+    if (E > 0) {
+        apply_Qf<C>(lds, st.tau, dxh, r);
+        double wz[SE];
+        mul_WT<C>(st, dlam, wz, r);
+#pragma unroll
+        for (int s = 0; s < SE; ++s) dnu[s] = inE[s] ? -(gy[s] + wz[s]) : 0.0;
+        solve_UT<C>(st, dnu, r);
+    }
+    tri_solve_T<SN, N>(lds + C::oLq, st.rdq, dxh, r);                   // dx = Lq^-T dxh
+
+    if (!live) return;
+    // gradients (qp.py:158-181); each lane writes its own rows
+#pragma unroll
+    for (int s = 0; s < SN; ++s)
+        if (P.dp && inN[s]) P.dp[qp * N + r + 16 * s] = dxh[s];
+#pragma unroll
+    for (int s = 0; s < SM; ++s)
+        if (P.dh && inM[s]) P.dh[qp * M + r + 16 * s] = -dlam[s];
+    if (E > 0) {
+#pragma unroll
+        for (int s = 0; s < SE; ++s)
+            if (P.db && inE[s]) P.db[qp * E + r + 16 * s] = -dnu[s];
+    }
+    // Outer products with lanes along the contiguous column axis: for row i the 16 lanes of the
+    // QP's DPP row write 16 consecutive doubles (one 128-byte segment) per slot.
+    if (P.dQ) {
+        double *o = P.dQ + qp * N * N;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const double dxi = BC(dxh, i), zi = BC(zh, i);
+#pragma unroll
+            for (int s = 0; s < SN; ++s)
+                if (inN[s]) o[i * N + r + 16 * s] = 0.5 * (dxi * zh[s] + zi * dxh[s]);
+        }
+    }
+    if (P.dG) {
+        double *o = P.dG + qp * M * N;
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const double dli = BC(dlam, i), li = BC(lam, i);
+#pragma unroll
+            for (int s = 0; s < SN; ++s)
+                if (inN[s]) o[i * N + r + 16 * s] = dli * zh[s] + li * dxh[s];
+        }
+    }
+    if (P.dA && E > 0) {
+        double *o = P.dA + qp * E * N;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+            const double dni = BC(dnu, i), ni = BC(nu, i);
+#pragma unroll
+            for (int s = 0; s < SN; ++s)
+                if (inN[s]) o[i * N + r + 16 * s] = dni * zh[s] + ni * dxh[s];
+        }
+    }
+    if (r == 0 && P.info) { P.info[2 * qp] = st.status; P.info[2 * qp + 1] = 0; }
+}
+
 template <class C, class K>
 int launch(K kernel, const KParams &P, void *stream)
 {
@@ -739,10 +898,18 @@ int launch(K kernel, const KParams &P, void *stream)
 #define DQP_CAT2(a, n, m, e) a##n##_##m##_##e
 #define DQP_CAT(a, n, m, e) DQP_CAT2(a, n, m, e)
 
+#ifndef DQP_R16_BWD
 int DQP_CAT(r16n_forward_, DQP_R16_N, DQP_R16_M, DQP_R16_E)(const KParams &P, void *stream)
 {
     using C = r16n::Cfg<DQP_R16_N, DQP_R16_M, DQP_R16_E>;
     return r16n::launch<C>(r16n::forward_kernel<C>, P, stream);
 }
+#else
+int DQP_CAT(r16n_backward_, DQP_R16_N, DQP_R16_M, DQP_R16_E)(const KParams &P, void *stream)
+{
+    using C = r16n::Cfg<DQP_R16_N, DQP_R16_M, DQP_R16_E>;
+    return r16n::launch<C>(r16n::backward_kernel<C>, P, stream);
+}
+#endif
 
 }  // namespace dqp

@@ -49,6 +49,21 @@ def test_argument_validation_without_gpu(lib):
     assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 14)) == 0    # empty batch: no launch
 
 
+def test_workspace_bytes_is_a_host_function(lib):
+    """include/dqp.h: optional forward scratch = nbatch * (neq (nz - neq) + neq (neq - 1) / 2) doubles
+    for the sizes that have a null-space kernel, 0 otherwise (generic kernels, no equalities)."""
+    from diff_qp_mpc_amd import _lib, _build
+    for nz, nineq, neq in _build.R16N_SIZES:
+        d = _lib.dqp_dims(7, nz, nineq, neq, 0, 0, 0, 0, 0, 0)
+        assert lib.dqp_workspace_bytes(ctypes.byref(d)) == 7 * (neq * (nz - neq) + neq * (neq - 1) // 2) * 8
+    for nz, nineq, neq in [(12, 8, 0), (7, 5, 2), (64, 64, 32)]:
+        d = _lib.dqp_dims(7, nz, nineq, neq, 0, 0, 0, 0, 0, 0)
+        assert lib.dqp_workspace_bytes(ctypes.byref(d)) == 0
+    d = _lib.dqp_dims(0, 30, 30, 15, 0, 0, 0, 0, 0, 0)
+    assert lib.dqp_workspace_bytes(ctypes.byref(d)) == 0
+    assert lib.dqp_workspace_bytes(None) == 0
+
+
 def test_mpc_argument_validation_without_gpu(lib):
     from diff_qp_mpc_amd import _lib
     z = ctypes.c_void_p(0)
