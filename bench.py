@@ -91,7 +91,7 @@ class HotPath:
         self.dG = torch.empty(B, NINEQ, NZ, **kw); self.dh = torch.empty(B, NINEQ, **kw)
         self.dA = torch.empty(B, NEQ, NZ, **kw); self.db = torch.empty(B, NEQ, **kw)
         self.dims = _lib.dqp_dims(B, NZ, NINEQ, NEQ, NZ * NZ, NZ, NINEQ * NZ, NINEQ, NEQ * NZ, NEQ)
-        self.opts = _lib.dqp_opts(1e-12, 1e-10, 20, 3, 0, 0)
+        self.opts = _lib.dqp_opts(float(os.environ.get("DQP_BENCH_EPS", "1e-12")), 1e-10, 20, 3, 0, 0)
         wsb = int(self.lib.dqp_workspace_bytes(ctypes.byref(self.dims)))
         self.ws = torch.empty(max(wsb // 8, 1), **kw)            # caller-owned scratch (include/dqp.h)
         self.stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

@@ -617,7 +617,13 @@ int fill_params(const dqp_dims *d, const dqp_opts *o, KParams &P, size_t &lds_by
     P.ldt = P.ldz > P.ldm ? P.ldz : P.ldm;
     P.sQ = d->stride_Q; P.sp = d->stride_p; P.sG = d->stride_G;
     P.sh = d->stride_h; P.sA = d->stride_A; P.sb = d->stride_b;
-    P.eps = o ? o->eps : 1e-12;
+    // per-problem exit threshold: one decade below the reference's batch-wide eps (include/dqp.h):
+    // a large batch never meets `best_resids.max() < eps` before maxIter, so the reference keeps
+    // polishing every problem; stopping exactly at eps left mu ~10x larger than the reference's
+    // and moved the gradients of weakly active constraints (lam ~ 1e-4) by up to 1e-3 relative
+    // (tools/stress_parity.py: 58 tolerance exceedances in 147k QPs -> 10 with the extra decade,
+    // the same as never stopping at eps at all; costs ~1 iteration on average).
+    P.eps = (o ? o->eps : 1e-12) * 0.1;
     P.stallTol = o ? o->stall_tol : 1e-10;
     P.maxIter = o ? o->max_iter : 20;
     P.notImprovedLim = o ? o->not_improved_lim : 3;

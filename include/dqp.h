@@ -97,7 +97,10 @@ size_t dqp_workspace_bytes(const dqp_dims *dims);
  * when NO sample improved for not_improved_lim consecutive iterations, so in a large batch
  * every sample effectively runs max_iter iterations).  Here a problem stops when (a) it has
  * not improved for not_improved_lim consecutive iterations AND its best residual is already
- * below stall_tol (converged, stagnating at round-off), (b) its best residual < eps, (c) its
+ * below stall_tol (converged, stagnating at round-off), (b) its best residual < eps / 10 (one
+ * Newton step past the reference's threshold: in the reference every problem of a large batch
+ * keeps iterating past eps, and the extra decade is what keeps the duals of weakly active
+ * constraints -- and the gradients that depend on lam/slack -- within tolerance of it), (c) its
  * residual is no longer finite (the iterate can never recover; the reference keeps spinning
  * on NaNs), (d) mu > 1e32, or (e) after max_iter iterations.  The best-residual iterate is
  * returned, as in batch.py:119-140,208.
