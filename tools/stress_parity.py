@@ -25,6 +25,30 @@ def family(seed, B, nz, nineq, neq, kind):
     b = (A @ z0.unsqueeze(-1)).squeeze(-1)
     return [t.numpy() for t in (Q, p, G, h, A, b)]
 
+def family_mpc(seed, B, n=3, m=3, T=5):
+    """MPC-structured dense QP (SURVEY 8d family M): block-diagonal cost, dynamics equalities
+    x_{t+1} = A x_t + B u_t, x_0 given, box |u| <= 1 (so many constraints are active)."""
+    rng = np.random.default_rng(seed)
+    nt, nz, neq, nineq = n + m, T * (n + m), T * n, 2 * T * m
+    Q = np.tile(np.eye(nz), (B, 1, 1)) * (0.5 + rng.random((B, 1, 1)))
+    p = rng.standard_normal((B, nz))
+    A = np.zeros((B, neq, nz)); b = np.zeros((B, neq))
+    Ad = np.eye(n) + 0.2 * rng.standard_normal((B, n, n)); Bd = rng.standard_normal((B, n, m))
+    for t in range(T - 1):
+        r0 = t * n
+        A[:, r0:r0 + n, t * nt:t * nt + n] = -Ad
+        A[:, r0:r0 + n, t * nt + n:(t + 1) * nt] = -Bd
+        A[:, r0:r0 + n, (t + 1) * nt:(t + 1) * nt + n] = np.eye(n)
+    A[:, (T - 1) * n:, :n] = np.eye(n)
+    b[:, (T - 1) * n:] = rng.standard_normal((B, n))
+    G = np.zeros((B, nineq, nz)); h = np.ones((B, nineq))
+    for t in range(T):
+        for i in range(m):
+            G[:, t * m + i, t * nt + n + i] = 1.0
+            G[:, T * m + t * m + i, t * nt + n + i] = -1.0
+    return [np.ascontiguousarray(a) for a in (Q, p, G, h, A, b)]
+
+
 oracle.build()
 qpmod.STALL_TOL = float(os.environ.get("STALL_TOL", qpmod.STALL_TOL))
 seeds = int(os.environ.get("SEEDS", "6"))
@@ -33,9 +57,11 @@ worst = {}
 bad = 0
 t0 = time.time()
 for (nz, nineq, neq) in _build.R16N_SIZES:
-    for kind in ("R", "D"):
+    for kind in os.environ.get("KINDS", "R,D,M").split(","):
+        if kind == "M" and (nz, nineq, neq) != (30, 30, 15):
+            continue
         for seed in range(seeds):
-            ins = family(1000 * seed + nz, B, nz, nineq, neq, kind)
+            ins = family_mpc(seed, B) if kind == "M" else family(1000 * seed + nz, B, nz, nineq, neq, kind)
             o = oracle.qp_forward(*ins)
             cm = o["best_resid"] < 1e-8
             dv = [torch.tensor(a, device="cuda") for a in ins]
@@ -49,9 +75,14 @@ for (nz, nineq, neq) in _build.R16N_SIZES:
                                           (True,) * 6, flag)
                 qpmod.FORCE_FLAGS = 0
                 torch.cuda.synchronize()
+                nexc = [0]
                 def dev_of(x, ref, m, rtol, atol):
                     x = x.cpu().numpy()[m]; ref = ref[m]
-                    return float(np.max(np.abs(x - ref) / (atol + rtol * np.abs(ref)))) if x.size else 0.0
+                    if not x.size:
+                        return 0.0
+                    e = np.abs(x - ref) / (atol + rtol * np.abs(ref))
+                    nexc[0] = max(nexc[0], int((e.reshape(e.shape[0], -1).max(1) > 1.0).sum()))
+                    return float(e.max())
                 devs = {"zhat": dev_of(zhat, o["zhat"], cm, 1e-6, 1e-8), "lam": dev_of(lam, o["lam"], cm, 1e-5, 1e-7),
                         "nu": dev_of(nu, o["nu"], cm, 1e-5, 1e-7), "slack": dev_of(slack, o["slack"], cm, 1e-5, 1e-7)}
                 for k, t in zip("QpGhAb", gr):
@@ -64,6 +95,8 @@ for (nz, nineq, neq) in _build.R16N_SIZES:
                     if v > 1.0:
                         bad += 1
                         print("EXCEEDS", fam, k, "%.2f x tolerance" % v, (nz, nineq, neq), kind, seed, flush=True)
+                if nexc[0]:
+                    print("   problems over tolerance in this batch (%s): %d of %d" % (fam, nexc[0], B), flush=True)
             print("size", (nz, nineq, neq), kind, "seed", seed, "converged %.4f" % cm.mean(), "status!=0:", st, "iters mean %.2f" % itmean,
                   "%.0fs" % (time.time() - t0), flush=True)
 print("worst deviation / tolerance per output:")
