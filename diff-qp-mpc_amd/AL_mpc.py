@@ -54,9 +54,9 @@ class MPC(Module):
         self.nineq = 2 * n_ctrl * T
         self.dyn_res_crit, self.dyn_res_factor = 1e-4, 10
         self.rho_prev = 1.0
-        self.lamda_prev = torch.zeros(n_batch, self.neq + self.nineq).to(self.u_upper)
+        self.lamda_prev = torch.zeros(n_batch, self.neq + self.nineq, dtype=self.u_upper.dtype, device=self.u_upper.device)
         self.dyn_res_prev = 1000000
-        self.mask = torch.ones(n_batch, T, 1).to(self.u_upper)
+        self.mask = torch.ones(n_batch, T, 1, dtype=self.u_upper.dtype, device=self.u_upper.device)
 
     # ------------------------------------------------------------------ AL_mpc.py:198-252
     def forward(self, x0, cost, dx, dx_jac, u_init=None, x_init=None):
@@ -70,7 +70,7 @@ class MPC(Module):
         if u_init is not None:
             u = batched(u_init)
         elif self.u_init is None:
-            u = torch.zeros(B, self.T, self.n_ctrl).type_as(x0.data)
+            u = torch.zeros(B, self.T, self.n_ctrl, dtype=x0.dtype, device=x0.device)
         else:
             u = batched(self.u_init)
         u = u.type_as(x0.data)

@@ -53,7 +53,8 @@ _lib = None
 
 
 def path():
-    return _build.SO
+    # DQP_HIP_LIBRARY: A/B runs of an alternative build of the same library (tools/, profiling)
+    return os.environ.get("DQP_HIP_LIBRARY") or _build.SO
 
 
 def load():

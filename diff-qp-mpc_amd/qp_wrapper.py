@@ -202,7 +202,8 @@ class MPC(Module):
 
         assert x0.ndimension() == 2 and x0.size(0) == n_batch
         if self.u_init is None:
-            u = torch.zeros(self.T, n_batch, self.n_ctrl).type_as(x0.data)
+            u = torch.zeros(self.T, n_batch, self.n_ctrl, dtype=x0.dtype, device=x0.device)   # on device:
+            # the reference builds it on the host and copies (qp_wrapper.py:174), a blocking H2D per call
         else:
             u = self.u_init
             if u.ndimension() == 2:
@@ -227,7 +228,7 @@ class MPC(Module):
         if isinstance(dx, LinDx):
             F, f = dx.F, dx.f
             if f is None:
-                f = torch.zeros((self.T - 1, self.n_batch, self.n_state)).to(x0)
+                f = torch.zeros((self.T - 1, self.n_batch, self.n_state), dtype=x0.dtype, device=x0.device)
         else:
             F, f = self.linearize_dynamics(x, detach_maybe(u), dx, dx_jac, diff=False)
         bounds = self.u_upper is not None
@@ -286,7 +287,7 @@ class MPC(Module):
 
     # ------------------------------------------------------------------ qp_wrapper.py:417-436
     def line_search(self, x, u, delta_x, delta_u, dx, x0, cost):
-        alpha = torch.ones([1, self.n_batch, 1]).to(x0)
+        alpha = torch.ones([1, self.n_batch, 1], dtype=x0.dtype, device=x0.device)
         cost_total = self.compute_cost(torch.cat((x, u), dim=2).transpose(0, 1), cost)
         for j in range(self.max_linesearch_iter):
             u_new = u + delta_u * alpha
