@@ -103,6 +103,9 @@ class HotPath:
                                      self.dA, self.db)]
         self.null = ctypes.c_void_p(0)
         self.wsp = P(self.ws) if wsb > 0 else self.null
+        # backward restarts from the factorisation context forward leaves in the workspace (what the
+        # reference keeps on ctx, qp.py:93-95)
+        self.bopts = self._lib.dqp_opts(0.0, 0.0, 0, 0, self._lib.DQP_FLAG_BACKWARD_CTX if wsb > 0 else 0, 0)
 
     def forward(self):
         rc = self.lib.dqp_qp_forward(ctypes.byref(self.dims), ctypes.byref(self.opts), *self.fargs,
@@ -111,8 +114,8 @@ class HotPath:
             raise RuntimeError("dqp_qp_forward rc=%d" % rc)
 
     def backward(self):
-        rc = self.lib.dqp_qp_backward(ctypes.byref(self.dims), ctypes.byref(self.opts), *self.bargs,
-                                      self.null, self.null, self.stream)
+        rc = self.lib.dqp_qp_backward(ctypes.byref(self.dims), ctypes.byref(self.bopts), *self.bargs,
+                                      self.null, self.wsp, self.stream)
         if rc:
             raise RuntimeError("dqp_qp_backward rc=%d" % rc)
 

@@ -57,7 +57,7 @@ def _jobs():
     cc = hipcc()
     jobs = []
     variants = [("r16f", "dqp_r16.hip", R16_SIZES, []), ("r16b", "dqp_r16.hip", R16_SIZES, ["-DDQP_R16_BWD"]),
-                ("r16n", "dqp_r16n.hip", R16N_SIZES, [])]
+                ("r16n", "dqp_r16n.hip", R16N_SIZES, []), ("r16nb", "dqp_r16n.hip", R16N_SIZES, ["-DDQP_R16_BWD"])]
     for tag, src, sizes, extra in variants:
         for n, m, e in sorted(sizes, key=lambda t: -t[0] * t[1]):        # longest compiles first
             obj = os.path.join(CSRC, "dqp_%s_%d_%d_%d.o" % (tag, n, m, e))

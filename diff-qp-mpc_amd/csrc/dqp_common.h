@@ -39,6 +39,8 @@ int r16_backward(const KParams &P, void *stream);
 // r16n_workspace_doubles(N, M, E) doubles per QP in P.workspace (0: no instantiation).
 int r16n_forward(const KParams &P, void *stream);
 long long r16n_workspace_doubles(int N, int M, int E);
+// backward restarted from the context r16n_forward left in P.workspace (DQP_FLAG_BACKWARD_CTX)
+int r16n_backward(const KParams &P, void *stream);
 
 }  // namespace dqp
 #endif

@@ -17,7 +17,9 @@ namespace dqp {
     int r16_backward_##n##_##m##_##e(const KParams &, void *);
 DQP_R16_SIZE_LIST
 #undef X
-#define X(n, m, e) int r16n_forward_##n##_##m##_##e(const KParams &, void *);
+#define X(n, m, e)                                                  \
+    int r16n_forward_##n##_##m##_##e(const KParams &, void *);      \
+    int r16n_backward_##n##_##m##_##e(const KParams &, void *);
 DQP_R16N_SIZE_LIST
 #undef X
 
@@ -45,9 +47,20 @@ int r16n_forward(const KParams &P, void *stream)
     return 1;
 }
 
+int r16n_backward(const KParams &P, void *stream)
+{
+#define X(n, m, e) if (P.N == n && P.M == m && P.E == e) return r16n_backward_##n##_##m##_##e(P, stream);
+    DQP_R16N_SIZE_LIST
+#undef X
+    return 1;
+}
+
 long long r16n_workspace_doubles(int N, int M, int E)
 {
-#define X(n, m, e) if (N == n && M == m && E == e) return (long long)e * (n - e) + (long long)e * (e - 1) / 2;
+#define X(n, m, e)                                                                          \
+    if (N == n && M == m && E == e)                                                         \
+        return (long long)e * (n - e) + (long long)e * (e - 1) / 2 + (long long)n * (n + 1) / 2 + \
+               (long long)m * n + (long long)e * e + 2 * e + n;   /* = r16n::Cfg::wsQP */
     DQP_R16N_SIZE_LIST
 #undef X
     return 0;

@@ -717,7 +717,7 @@ __attribute__((visibility("default"))) int
 dqp_qp_backward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, const double *G,
                 const double *A, const double *zhat, const double *lam, const double *nu,
                 const double *slack, const double *dl_dzhat, double *dQ, double *dp, double *dG,
-                double *dh, double *dA, double *db, int32_t *info, void * /*workspace*/,
+                double *dh, double *dA, double *db, int32_t *info, void *workspace,
                 void *stream)
 {
     KParams P = {};
@@ -731,12 +731,14 @@ dqp_qp_backward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, con
     P.zin = zhat; P.lamin = lam; P.nuin = nu; P.slackin = slack; P.gin = dl_dzhat;
     P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db;
     P.info = info;
+    P.workspace = (double *)workspace;
     if (!(P.flags & DQP_FLAG_GENERIC_ONLY)) {
-        // Backward is ONE solve, always in the Schur-complement form (T = R + D^-1 keeps dlam
-        // accurate for strongly active constraints, d ~ 1e8 after the reference's clamps).  A
-        // null-space backward (dqp_r16n.hip: backward_kernel, -DDQP_R16_BWD) exists and is parity
-        // green, but its setup spills under this compiler (0.30 ms vs 0.07 ms), so it is not built.
-        rc = r16_backward(P, stream);
+        // Backward is ONE solve, always in the Schur-complement form (T = Gz Gz^T + D^-1 keeps
+        // dlam accurate for strongly active constraints, d ~ 1e8 after the reference's clamps).
+        // With the forward's workspace (DQP_FLAG_BACKWARD_CTX) nothing is refactored.
+        rc = ((P.flags & DQP_FLAG_BACKWARD_CTX) && workspace && !(P.flags & DQP_FLAG_NO_NULLSPACE))
+                 ? r16n_backward(P, stream) : 1;
+        if (rc == 1) rc = r16_backward(P, stream);
         if (rc != 1) return rc;
     }
     const int mx = P.N > P.M ? (P.N > P.E ? P.N : P.E) : (P.M > P.E ? P.M : P.E);

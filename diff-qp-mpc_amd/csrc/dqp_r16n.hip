@@ -55,6 +55,13 @@ template <int N_, int M_, int E_> struct Cfg {
     static constexpr int ldsQP = oDummy + 16;
     static constexpr int ldsQPpad = (ldsQP + 1) & ~1;
     __host__ __device__ static constexpr int toff(int k) { return k * (N_ - E_) + k * (k - 1) / 2; }
+    // caller workspace per QP (doubles): the reflector tails (parked during the iteration), then
+    // the factorisation context the backward pass restarts from -- what the reference keeps on
+    // ctx (Q_LU, S_LU, R: qp.py:93-95): packed Lq, [Gz | W] and U column-major, tau, 1/diag(U),
+    // 1/diag(Lq)
+    static constexpr int wTl = 0, wLq = tailsz, wG = wLq + tri(N_), wU = wG + M_ * N_;
+    static constexpr int wTau = wU + E_ * E_, wRdu = wTau + E_, wRdq = wRdu + E_;
+    static constexpr int wsQP = wRdq + N_;
 };
 
 template <class C> struct State {
@@ -445,9 +452,33 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
 
     // H: the reflector tails are done for now: park them in the caller's workspace (read back
     // for the epilogue), then Rm = Gz Gz^T goes, packed, into the same LDS region.
-    if (E > 0) {
-        double *ws = P.workspace + qp * (long long)C::tailsz;
-        for (int e = r; e < C::tailsz; e += 16) ws[e] = lds[C::oTl + e];
+    {
+        double *ws = P.workspace + qp * (long long)C::wsQP;
+        for (int e = r; e < C::tailsz; e += 16) ws[C::wTl + e] = lds[C::oTl + e];
+        for (int e = r; e < tri(N); e += 16) ws[C::wLq + e] = lds[C::oLq + e];
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            const int i = r + 16 * s;
+            if (i < M) {
+#pragma unroll
+                for (int c = 0; c < N; ++c) ws[C::wG + c * M + i] = st.Gh[s][c];   // column-major: the 16
+                // lanes of a QP write 16 consecutive doubles (row-major 8-byte stores 240 B apart
+                // cost 5x write amplification in HBM)
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SE; ++s) {
+            const int k = r + 16 * s;
+            if (k < E) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) ws[C::wU + e * E + k] = st.Ah[s][R + e];
+                ws[C::wTau + k] = st.tau[s];
+                ws[C::wRdu + k] = st.rdu1[s];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SN; ++s)
+            if (r + 16 * s < N) ws[C::wRdq + r + 16 * s] = st.rdq[s];
     }
     __syncthreads();
     {
@@ -678,7 +709,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     // the reflector tails come back from the workspace into the (now idle) Gz Gz^T region
     __syncthreads();
     if (E > 0) {
-        const double *ws = P.workspace + qp * (long long)C::tailsz;
+        const double *ws = P.workspace + qp * (long long)C::wsQP + C::wTl;
         for (int e = r; e < C::tailsz; e += 16) lds[C::oTl + e] = ws[e];
     }
     __syncthreads();
@@ -729,8 +760,9 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
 // gq = Qf^T Lq^-1 g split into its null-space part gz and range part gy:
 //   (Gz Gz^T + diag(s/lam)) dlam = -Gz gz,   dw = -(gz + Gz^T dlam),   dx = Lq^-T Qf [dw ; 0],
 //   dnu = -U^-T (gy + W^T dlam).
-// Only the factorisations A-C of setup are needed, T is accumulated straight into registers
-// (no packed Gz Gz^T in LDS, so the reflectors stay resident and no workspace is used).
+// Nothing is refactored: Lq, the reflectors, [Gz | W] and U come back from the workspace the
+// forward kernel of the same (Q, G, A) filled (DQP_FLAG_BACKWARD_CTX), like the reference's
+// ctx.Q_LU / S_LU / R; T is accumulated straight into registers.
 template <class C>
 __global__ __launch_bounds__(64) void backward_kernel(KParams P)
 {
@@ -744,7 +776,42 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P)
     double *lds = sm + qrow * C::ldsQPpad;
 
     State<C> st;
-    setup<C, false>(P, qp, r, lds, st);
+    st.status = DQP_STATUS_OK;
+    {
+        const double *ws = P.workspace + qp * (long long)C::wsQP;
+        for (int e = r; e < C::tailsz; e += 16) lds[C::oTl + e] = ws[C::wTl + e];
+        for (int e = r; e < tri(N); e += 16) lds[C::oLq + e] = ws[C::wLq + e];
+#pragma unroll
+        for (int s = 0; s < SM; ++s) {
+            const int i = r + 16 * s, ic = i < M ? i : M - 1;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const double v = ws[C::wG + c * M + ic];
+                st.Gh[s][c] = (16 * s + 15 >= M) ? mask_hi(v, i < M) : v;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < SE; ++s) {
+            const int k = r + 16 * s, kc = k < E ? k : E - 1;
+#pragma unroll
+            for (int c = 0; c < N; ++c) st.Ah[s][c] = 0.0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double v = ws[C::wU + e * E + kc];
+                st.Ah[s][R + e] = k < E ? v : 0.0;
+            }
+            const double t = ws[C::wTau + kc], u = ws[C::wRdu + kc];
+            st.tau[s] = k < E ? t : 0.0;
+            st.rdu1[s] = k < E ? u : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < SN; ++s) {
+            const int i = r + 16 * s;
+            const double v = ws[C::wRdq + (i < N ? i : N - 1)];
+            st.rdq[s] = i < N ? v : 0.0;
+        }
+    }
+    __syncthreads();
 
     bool inN[SN], inM[SM], inE[SE];
 #pragma unroll

@@ -102,12 +102,14 @@ def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim):
                                 _ptr(h), _ptr(A), _ptr(b), _ptr(zhat), _ptr(lam), _ptr(nu),
                                 _ptr(slack), _ptr(info), _ptr(resid), _ptr(ws), _stream(dev))
     _lib.check(rc, "dqp_qp_forward")
-    return zhat, lam, nu, slack, info, resid, (Q, G, A, dims)
+    # the workspace now holds the factorisation context backward can restart from (include/dqp.h)
+    ctx_ws = ws if (ws is not None and not (FORCE_FLAGS & (_lib.DQP_FLAG_NO_NULLSPACE | _lib.DQP_FLAG_GENERIC_ONLY))) else None
+    return zhat, lam, nu, slack, info, resid, (Q, G, A, dims, ctx_ws)
 
 
 def _backward_impl(saved, zhat, lam, nu, slack, dl_dzhat, need, flags):
     lib = _lib.load()
-    Q, G, A, dims = saved
+    Q, G, A, dims, ctx_ws = saved
     nBatch, nz, nineq, neq = dims.nbatch, dims.nz, dims.nineq, dims.neq
     dev = Q.device
     kw = dict(dtype=torch.float64, device=dev)
@@ -118,12 +120,14 @@ def _backward_impl(saved, zhat, lam, nu, slack, dl_dzhat, need, flags):
     dh = torch.empty(nBatch, nineq, **kw) if need[3] else None
     dA = torch.empty(nBatch, neq, nz, **kw) if (need[4] and neq > 0) else None
     db = torch.empty(nBatch, neq, **kw) if (need[5] and neq > 0) else None
+    if ctx_ws is not None and not (FORCE_FLAGS & (_lib.DQP_FLAG_NO_NULLSPACE | _lib.DQP_FLAG_GENERIC_ONLY)):
+        flags |= _lib.DQP_FLAG_BACKWARD_CTX
     opts = _lib.dqp_opts(0.0, 0.0, 0, 0, flags | FORCE_FLAGS, 0)
     with torch.cuda.device(dev):
         rc = lib.dqp_qp_backward(ctypes.byref(dims), ctypes.byref(opts), _ptr(Q), _ptr(G), _ptr(A),
                                  _ptr(zhat), _ptr(lam), _ptr(nu), _ptr(slack), _ptr(g),
                                  _ptr(dQ), _ptr(dp), _ptr(dG), _ptr(dh), _ptr(dA), _ptr(db),
-                                 ctypes.c_void_p(0), ctypes.c_void_p(0), _stream(dev))
+                                 ctypes.c_void_p(0), _ptr(ctx_ws), _stream(dev))
     _lib.check(rc, "dqp_qp_backward")
     return dQ, dp, dG, dh, dA, db
 

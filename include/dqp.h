@@ -52,6 +52,10 @@ enum {
                                       without the 1e-8 clamps of QPFunction (qp.py:149)   */
 
 #define DQP_FLAG_GENERIC_ONLY 2u   /* testing: skip the size-specialised DPP-row kernels     */
+#define DQP_FLAG_BACKWARD_CTX 8u   /* dqp_qp_backward: `workspace` is the buffer dqp_qp_forward filled
+                                      for the SAME Q, G, A (it holds the factorisations, like the
+                                      reference's ctx.Q_LU / S_LU / R, qp.py:93-95): skip the
+                                      refactorisation.  Ignored where no such kernel exists.   */
 #define DQP_FLAG_NO_NULLSPACE 4u   /* forward: keep the equality rows in the iteration even when a
                                       workspace is given (the kernel used without one)       */
 
@@ -76,12 +80,14 @@ typedef struct dqp_opts {
 int dqp_version(void);
 const char *dqp_error_string(int code);
 
-/* Bytes of caller-provided device workspace for dqp_qp_forward (8-byte aligned; contents are
- * scratch).  Optional: with workspace == NULL, or a size for which this returns 0, every
- * solver state lives in LDS/registers.  With it, the size-specialised forward kernels
- * eliminate the equality constraints once (null-space form) and park the elimination's
- * reflectors there between setup and the final back-transformation -- ~1.4x faster at the
- * metric size, same iterates in exact arithmetic.  dqp_qp_backward needs none. */
+/* Bytes of caller-provided device workspace for dqp_qp_forward (8-byte aligned).  Optional:
+ * with workspace == NULL, or a size for which this returns 0, every solver state lives in
+ * LDS/registers.  With it, the size-specialised forward kernels eliminate the equality
+ * constraints once (null-space form), park the elimination's reflectors there between setup and
+ * the final back-transformation -- ~1.4x faster at the metric size, same iterates in exact
+ * arithmetic -- and leave the factorisation context (Lq, reflectors, [Gz | W], U; ~16 KB per QP at
+ * the metric size) for dqp_qp_backward: pass the same buffer with DQP_FLAG_BACKWARD_CTX to skip
+ * the refactorisation (2x faster backward).  Without that flag backward needs no workspace. */
 size_t dqp_workspace_bytes(const dqp_dims *dims);
 
 /*

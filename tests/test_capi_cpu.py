@@ -50,12 +50,14 @@ def test_argument_validation_without_gpu(lib):
 
 
 def test_workspace_bytes_is_a_host_function(lib):
-    """include/dqp.h: optional forward scratch = nbatch * (neq (nz - neq) + neq (neq - 1) / 2) doubles
-    for the sizes that have a null-space kernel, 0 otherwise (generic kernels, no equalities)."""
+    """include/dqp.h: optional workspace per QP = reflector tails + the factorisation context
+    (packed Lq, [Gz | W], U, tau, 1/diag U, 1/diag Lq) for the sizes that have a null-space
+    kernel, 0 otherwise (generic kernels, no equalities)."""
     from diff_qp_mpc_amd import _lib, _build
     for nz, nineq, neq in _build.R16N_SIZES:
         d = _lib.dqp_dims(7, nz, nineq, neq, 0, 0, 0, 0, 0, 0)
-        assert lib.dqp_workspace_bytes(ctypes.byref(d)) == 7 * (neq * (nz - neq) + neq * (neq - 1) // 2) * 8
+        per_qp = (neq * (nz - neq) + neq * (neq - 1) // 2) + nz * (nz + 1) // 2 + nineq * nz + neq * neq + 2 * neq + nz
+        assert lib.dqp_workspace_bytes(ctypes.byref(d)) == 7 * per_qp * 8
     for nz, nineq, neq in [(12, 8, 0), (7, 5, 2), (64, 64, 32)]:
         d = _lib.dqp_dims(7, nz, nineq, neq, 0, 0, 0, 0, 0, 0)
         assert lib.dqp_workspace_bytes(ctypes.byref(d)) == 0

@@ -246,7 +246,8 @@ def test_workspace_is_optional(dqp):
     Q, p, G, h, A, b = [dev(g["in_" + k], grad=False) for k in "QpGhAb"]
     B, nz, nineq, neq = 8, 30, 30, 15
     dims = _lib.dqp_dims(B, nz, nineq, neq, nz * nz, nz, nineq * nz, nineq, neq * nz, neq)
-    assert lib.dqp_workspace_bytes(ctypes.byref(dims)) == B * (15 * 15 + 15 * 14 // 2) * 8
+    per_qp = (15 * 15 + 15 * 14 // 2) + 30 * 31 // 2 + 30 * 30 + 15 * 15 + 2 * 15 + 30
+    assert lib.dqp_workspace_bytes(ctypes.byref(dims)) == B * per_qp * 8
     odd = _lib.dqp_dims(B, 7, 5, 2, 49, 7, 35, 5, 14, 2)
     assert lib.dqp_workspace_bytes(ctypes.byref(odd)) == 0         # generic kernels: no scratch
     opts = _lib.dqp_opts(1e-12, 1e-10, 20, 3, 0, 0)
@@ -256,7 +257,7 @@ def test_workspace_is_optional(dqp):
         kw = dict(dtype=torch.float64, device="cuda")
         zhat, lam, nu, slack = (torch.empty(B, n, **kw) for n in (nz, nineq, neq, nineq))
         info = torch.empty(B, 2, dtype=torch.int32, device="cuda")
-        ws = torch.empty(B * 330, **kw)
+        ws = torch.empty(B * per_qp, **kw)
         rc = lib.dqp_qp_forward(ctypes.byref(dims), ctypes.byref(opts), P(Q), P(p), P(G), P(h), P(A),
                                 P(b), P(zhat), P(lam), P(nu), P(slack), P(info), None,
                                 P(ws) if use_ws else None, None)
