@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_PEAK_TFLOPS = 78.6      # public MI355X spec (vector = matrix fp64); not in the guide
 # ~50 kFLOP per PDIPM iteration + 0.27 MFLOP one-time factorisations per QP
 FLOP_SETUP, FLOP_PER_ITER = 0.27e6, 50e3
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "v6_final_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r1", "v7_final_pmc_summary.json")
 
 
 def measured_traffic(kernel_key):
