@@ -232,8 +232,10 @@ def main():
                          "achieved": fwd_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": fwd_gbs / HBM_PEAK_GBS, "traffic": measured_traffic("forward"),
                          "avg_launch_ms": fwd_ms, "algorithmic_bytes_per_launch": fwd_bytes,
-                         "note": "the path is fp64-issue bound, not HBM bound (DESIGN.md §4): "
-                                 "fp64 fraction below"},
+                         "note": "the path is fp64-issue bound, not HBM bound (DESIGN.md §4): fp64 "
+                                 "fraction below; measured traffic = algorithmic inputs/outputs + 65 MB "
+                                 "factorisation context written for backward (which then reads it "
+                                 "instead of Q,G,A) + 21 MB reflector round trip + setup spills"},
             "fp64": {"achieved_tflops": fwd_flops / (fwd_ms * 1e-3) / 1e12,
                      "peak_tflops": FP64_PEAK_TFLOPS,
                      "frac": fwd_flops / (fwd_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
