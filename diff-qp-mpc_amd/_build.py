@@ -23,7 +23,12 @@ R16_SIZES = [
     (10, 5, 3), (12, 8, 0),   # small test sizes (with / without equalities)
 ]
 # null-space form of the forward kernel (csrc/dqp_r16n.hip): every size above with equalities
-R16N_SIZES = [s for s in R16_SIZES if s[2] > 0]
+R16N_SIZES = [s for s in R16_SIZES if s[2] > 0] + [
+    # T = 10 / n = 6 MPC shapes: nz > 32 (3 register slots in setup, which spills -- it runs once),
+    # but nz - neq is 10 and 5, so the iteration is tiny.  Forward + context backward only.
+    (40, 20, 30),   # n=3 m=1 T=10 (BASELINE config 2: data/pendulum.pkl)
+    (35, 10, 30),   # n=6 m=1 T=5  (cartpole-2)
+]
 
 PLAIN_SOURCES = ["dqp_pdipm.hip", "dqp_mpc.hip", "dqp_al.hip"]
 SOURCES = PLAIN_SOURCES + ["dqp_r16.hip", "dqp_r16n.hip", "dqp_dispatch.hip"]
