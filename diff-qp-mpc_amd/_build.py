@@ -72,7 +72,17 @@ def _jobs():
     for src in PLAIN_SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         jobs.append((obj, [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]))
-    jobs.sort(key=lambda j: 0 if ("_30_30_15" in j[0] or "pdipm" in j[0]) else 1)
+    # longest compiles first (the 3-slot null-space forwards take ~4 min each, the metric-size
+    # kernels ~2-3 min, everything else seconds): keeps the wall time near total CPU / cores
+    def cost(j):
+        name = os.path.basename(j[0])
+        m = [int(t) for t in name.replace(".o", "").split("_")[-3:]] if name.count("_") >= 4 else None
+        if m is None:
+            return 5 if "pdipm" in name else 1
+        n, mm, e = m
+        w = n * n * (n + mm)
+        return w * (4 if "_r16n_" in name else (1 if "_r16nb_" in name else 2))
+    jobs.sort(key=cost, reverse=True)
     lst = lambda sizes: " ".join("X(%d,%d,%d)" % s for s in sizes)
     obj = os.path.join(CSRC, "dqp_dispatch.o")
     jobs.append((obj, [cc] + FLAGS + ["-DDQP_R16_SIZE_LIST=" + lst(R16_SIZES),
