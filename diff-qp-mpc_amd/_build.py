@@ -78,7 +78,7 @@ def _jobs():
         name = os.path.basename(j[0])
         m = [int(t) for t in name.replace(".o", "").split("_")[-3:]] if name.count("_") >= 4 else None
         if m is None:
-            return 5 if "pdipm" in name else 1
+            return 10 ** 9 if "pdipm" in name else 1          # the generic kernels: ~2 min
         n, mm, e = m
         w = n * n * (n + mm)
         return w * (4 if "_r16n_" in name else (1 if "_r16nb_" in name else 2))
@@ -114,6 +114,7 @@ def build(force=False, verbose=False, max_parallel=None):
     todo = [j for j in jobs if force or not _object_current(*j)]
     all_jobs, jobs = jobs, todo
     max_parallel = max_parallel or max(1, min(len(jobs), (os.cpu_count() or 2)))
+    import time
     pending, running = list(jobs), []
     while pending or running:
         while pending and len(running) < max_parallel:
@@ -121,13 +122,22 @@ def build(force=False, verbose=False, max_parallel=None):
             if verbose:
                 print(" ".join(cmd))
             running.append((subprocess.Popen(cmd), cmd))
-        pr, cmd = running.pop(0)
-        if pr.wait() != 0:
-            for other, _ in running:
-                other.kill()
-            raise subprocess.CalledProcessError(pr.returncode, cmd)
-        with open(cmd[-1] + ".cmd", "w") as f:
-            f.write(" ".join(cmd))
+        still = []
+        for pr, cmd in running:            # refill a slot as soon as ANY compile finishes
+            rc = pr.poll()
+            if rc is None:
+                still.append((pr, cmd))
+            elif rc != 0:
+                for other, _ in running:
+                    if other.poll() is None:
+                        other.kill()
+                raise subprocess.CalledProcessError(rc, cmd)
+            else:
+                with open(cmd[-1] + ".cmd", "w") as f:
+                    f.write(" ".join(cmd))
+        if len(still) == len(running):
+            time.sleep(0.2)
+        running = still
     subprocess.check_call([hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", SO] +
                           [obj for obj, _ in all_jobs])
     return SO

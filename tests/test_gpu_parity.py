@@ -125,7 +125,8 @@ def test_dense_vs_golden(dqp, name):
 
 @pytest.mark.parametrize("shape", [(64, 30, 30, 15), (33, 40, 20, 30), (17, 7, 64, 3),
                                    (9, 64, 64, 32), (5, 1, 1, 1), (130, 12, 9, 0),
-                                   (70, 20, 10, 15), (41, 15, 10, 10), (23, 25, 10, 20)])
+                                   (70, 20, 10, 15), (41, 15, 10, 10), (23, 25, 10, 20),
+                                   (37, 35, 10, 30), (6, 10, 5, 3)])
 def test_vs_oracle_seeded(dqp, shape):
     B, nz, nineq, neq = shape
     Q, p, G, h, A, b = family_R(100 + nz, B, nz, nineq, max(neq, 1))
