@@ -61,7 +61,7 @@ __device__ __forceinline__ double rcp_nr(double d)
 // x <- (L L^T)^-1 b    (!UNIT: LDS holds the Cholesky factor), on ONE wavefront, no barriers.
 // Element i of the vector lives on lane i & 63, slot i >> 6 (nz <= 128).  Columns are fetched
 // eight steps ahead of the substitution chain, so a step costs one readlane pair and one FMA.
-template <bool UNIT>
+template <bool UNIT, bool FORWARD = true>
 __device__ __forceinline__ void wave_solve(const double *H, int ld, int nz, int zidx, double (&b)[2], int lane)
 {
     double dg[2], rdg[2];
@@ -104,9 +104,11 @@ __device__ __forceinline__ void wave_solve(const double *H, int ld, int nz, int 
     }
 #define DQP_AL_ROTATE() _Pragma("unroll") for (int u = 0; u < G; ++u) { mc[u][0] = mn[u][0]; mc[u][1] = mn[u][1]; }
     const int nzg = ((nz + G - 1) / G) * G, lo_end = min(nzg, 64);
-    load_fwd(mn, 0);
-    for (int k0 = 0; k0 < lo_end; k0 += G) { DQP_AL_ROTATE(); load_fwd(mn, k0 + G); DQP_AL_CHAIN(0, 1); }
-    for (int k0 = 64; k0 < nzg; k0 += G) { DQP_AL_ROTATE(); load_fwd(mn, k0 + G); DQP_AL_CHAIN(1, 1); }
+    if (FORWARD) {
+        load_fwd(mn, 0);
+        for (int k0 = 0; k0 < lo_end; k0 += G) { DQP_AL_ROTATE(); load_fwd(mn, k0 + G); DQP_AL_CHAIN(0, 1); }
+        for (int k0 = 64; k0 < nzg; k0 += G) { DQP_AL_ROTATE(); load_fwd(mn, k0 + G); DQP_AL_CHAIN(1, 1); }
+    }
     if (UNIT) { b[0] *= rdg[0] * rdg[0]; b[1] *= rdg[1] * rdg[1]; }   // D^-1, d = (sqrt d)^2
     load_bwd(mn, nzg - 1);
     for (int k0 = nzg - 1; k0 >= 64; k0 -= G) { DQP_AL_ROTATE(); load_bwd(mn, k0 - G); DQP_AL_CHAIN(1, -1); }
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(256) void al_newton_kernel(AlP P)
     // applies the rank-1 update to its registers -- next pivot column first, so its owners
     // publish it before the bulk of the update (look-ahead).  Columns stay unscaled (c_ik) with
     // the pivot d_k on the diagonal: H = M D M^T, M_ik = c_ik / d_k.
+    const bool fused = nz < 16 * NT;       // row nz exists in the 16-cyclic grid (nz not a multiple of 16)
     double hr[NT * (NT + 1) / 2];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -247,6 +250,9 @@ __global__ __launch_bounds__(256) void al_newton_kernel(AlP P)
             const int row = ty + 16 * a, col = tx + 16 * b;
             hr[TRI(a, b)] = (row < nz && col <= row) ? H[row * ld + col] : 0.0;
             if (a == b) hr[TRI(a, b)] += qd[a];
+            // augmented row nz = rhs^T: the elimination then carries out the forward substitution
+            // M w = -grad for free (row nz ends up holding w), so wave 0 only has the backward sweep
+            if (fused && row == nz && col < nz) hr[TRI(a, b)] = -P.grad[prob * nz + col];
         }
     __syncthreads();
     double *colbuf = sm;                 // 2 x 128 doubles, aliases the (now unused) H region
@@ -316,6 +322,16 @@ __global__ __launch_bounds__(256) void al_newton_kernel(AlP P)
                 if (row < nz && col <= row) H[row * ld + col] = col == row ? sdc[b] : hr[TRI(a, b)] * rdc[b];
             }
     }
+    double *wvec = sm + P.flag_off + 2;    // row nz of the elimination = w (fused forward sweep)
+    if (fused && ty == (nz & 15)) {
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+            if ((nz >> 4) >= b && tx + 16 * b < nz) {
+#pragma unroll
+                for (int a = 0; a < NT; ++a)
+                    if (a >= b && a == (nz >> 4)) wvec[tx + 16 * b] = hr[TRI(a, b)];
+            }
+    }
     __syncthreads();
     const int info = firstbad;
     AL_STAMP(4);
@@ -324,8 +340,14 @@ __global__ __launch_bounds__(256) void al_newton_kernel(AlP P)
     if (wave == 0) {
         double b[2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) b[s] = (lane + 64 * s < nz) ? -P.grad[prob * nz + lane + 64 * s] : 0.0;
-        if (info == 0) wave_solve<true>(H, ld, nz, P.flag_off + 1, b, lane);
+        for (int s = 0; s < 2; ++s) {
+            const int i = lane + 64 * s;
+            b[s] = i < nz ? (fused ? wvec[i] : -P.grad[prob * nz + i]) : 0.0;
+        }
+        if (info == 0) {
+            if (fused) wave_solve<true, false>(H, ld, nz, P.flag_off + 1, b, lane);
+            else wave_solve<true, true>(H, ld, nz, P.flag_off + 1, b, lane);
+        }
         const double nanv = __longlong_as_double(0x7ff8000000000000LL);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
@@ -388,7 +410,7 @@ int fill(const dqp_al_dims *d, AlP &P, size_t &lds)
     if (hd < 256) hd = 256;           // the double-buffered pivot column of the factorisation
     P.chunk_rows = (int)((hd / nzp) & ~(size_t)3);
     P.flag_off = (int)hd;
-    lds = (hd + 2) * sizeof(double);
+    lds = (hd + 2 + 128) * sizeof(double);   // + zero word, + the fused forward-sweep result
     if (lds > 160 * 1024 - 64) return DQP_ERR_TOO_LARGE;
     return DQP_OK;
 }
