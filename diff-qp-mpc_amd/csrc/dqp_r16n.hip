@@ -1,4 +1,5 @@
-// dqp_r16n.hip -- DPP-row forward kernel, null-space form (4 QPs per wavefront).
+// dqp_r16n.hip -- DPP-row kernels, null-space form (4 QPs per wavefront): the default forward and
+// the backward that restarts from the forward's factorisation context.
 //
 // Same layout idea as dqp_r16.hip (one QP per 16-lane DPP row, matrices row-distributed in
 // registers, v_mov_b64_dpp row_newbcast as the only cross-lane primitive) but the equality
@@ -27,7 +28,11 @@
 // epilogue and the packed Gz Gz^T during the iteration (the tails wait in the caller's
 // workspace, dqp_workspace_bytes), then the parked vectors.
 //
-// Reference functions covered: a2-a7 of SURVEY.md §8 (as dqp_pdipm.hip / dqp_r16.hip).
+// The same workspace then carries the factorisation context (packed Lq, the tails, [Gz | W], U)
+// to backward_kernel (-DDQP_R16_BWD objects), which therefore has no setup at all -- the
+// counterpart of the reference keeping Q_LU / S_LU / R on ctx (qp.py:93-95).
+//
+// Reference functions covered: a2-a8 of SURVEY.md §8 (as dqp_pdipm.hip / dqp_r16.hip).
 
 #include "dqp_r16_prims.h"
 
@@ -217,9 +222,7 @@ __device__ __forceinline__ void mul_WT(const State<C> &st, const double (&v)[C::
 }
 
 // ------------------------------------------------------------------------------------------
-// FWD = false (backward pass): only the factorisations A-C run (p, h, b are not given and the
-// reduced cost vector / h' / Lq Z / Gz Gz^T are not needed).
-template <class C, bool FWD>
+template <class C>
 __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, double *lds, State<C> &st)
 {
     constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
@@ -230,11 +233,11 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     // latency hides under the factorisations instead of serialising three more round trips
     double p0[SN], h0[SM], b0[SE];
 #pragma unroll
-    for (int s = 0; s < SN; ++s) p0[s] = (FWD && r + 16 * s < N) ? P.p[qp * P.sp + r + 16 * s] : 0.0;
+    for (int s = 0; s < SN; ++s) p0[s] = (r + 16 * s < N) ? P.p[qp * P.sp + r + 16 * s] : 0.0;
 #pragma unroll
-    for (int s = 0; s < SM; ++s) h0[s] = (FWD && r + 16 * s < M) ? P.h[qp * P.sh + r + 16 * s] : 0.0;
+    for (int s = 0; s < SM; ++s) h0[s] = (r + 16 * s < M) ? P.h[qp * P.sh + r + 16 * s] : 0.0;
 #pragma unroll
-    for (int s = 0; s < SE; ++s) b0[s] = (FWD && E > 0 && r + 16 * s < E) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
+    for (int s = 0; s < SE; ++s) b0[s] = (E > 0 && r + 16 * s < E) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
     {   // A: Q -> Lq -> packed LDS
         double Lq[SN][N];
         load_rows<SN, N>(P.Q + qp * P.sQ, N, Lq, r);
@@ -334,7 +337,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         __builtin_amdgcn_sched_barrier(0);
 
         // D: xy = U^-1 b
-        if (FWD) {
+        {
             double b[SE];
 #pragma unroll
             for (int s = 0; s < SE; ++s) b[s] = b0[s];
@@ -354,7 +357,6 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (!FWD) return;
 
     {   // E: ph = Lq^-1 p ; [cp ; py] = Qf^T ph
         double ph[SN];
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     double *dummy = lds + C::oDummy + r;
 
     State<C> st;
-    setup<C, true>(P, qp, r, lds, st);
+    setup<C>(P, qp, r, lds, st);
 
     bool inM[SM], inR[SR];
 #pragma unroll
