@@ -141,8 +141,6 @@ class MPC(Module):
         assert max_linesearch_iter > 0
         if solver_type != 'dense':
             raise NotImplementedError("only solver_type='dense' exists in the reference too")
-        if add_goal_constraint:
-            raise NotImplementedError("add_goal_constraint (qp_wrapper.py:657-662) is not built yet")
         self.n_state, self.n_ctrl, self.T = n_state, n_ctrl, T
         self.u_lower, self.u_upper, self.x_goal = u_lower, u_upper, x_goal
         if not isinstance(u_lower, float):
@@ -239,6 +237,15 @@ class MPC(Module):
             ul, uu = as_t(self.u_lower), as_t(self.u_upper)
         Q, q, G, h, A, b = _AssembleDenseQP.apply(cost.C, cost.c, F, f, x0, ul, uu,
                                                   self.n_state, self.n_ctrl, self.T)
+        if self.add_goal_constraint:
+            # n_state more equality rows pinning the last state to the goal, which the reference
+            # hard-wires to zero ("b[...] = x0*0 # set to goal", qp_wrapper.py:650-652)
+            n, nt = self.n_state, self.n_state + self.n_ctrl
+            Ag = torch.zeros(self.n_batch, n, self.T * nt, dtype=A.dtype, device=A.device)
+            ar = torch.arange(n, device=A.device)
+            Ag[:, ar, (self.T - 1) * nt + ar] = 1.0
+            A = torch.cat([A, Ag], 1)
+            b = torch.cat([b, torch.zeros(self.n_batch, n, dtype=b.dtype, device=b.device)], 1)
         xhats_qpf = DenseQPFunction()(Q, q, G, h, A, b, None).to(x0.dtype)
         xhats_qpf = xhats_qpf.reshape(self.n_batch, self.T, -1)
         x_hat = xhats_qpf[:, :, :self.n_state].transpose(0, 1)

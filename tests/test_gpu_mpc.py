@@ -78,6 +78,25 @@ def test_mpc_forward_backward_vs_golden(name, n, m, T, tag, kw):
                                    err_msg="%s d%s" % (tag, k))
 
 
+def test_mpc_goal_constraint_vs_golden():
+    """MPC(add_goal_constraint=True): the reference's extra terminal-state equality rows
+    (qp_wrapper.py:638-656); fixture from tests/golden/make_golden_goal.py."""
+    from diff_qp_mpc_amd.qp_wrapper import MPC, QuadCost, LinDx
+    g = load("G_goal_b4")
+    B, n, m, T = 4, 3, 2, 4
+    C, c, F, f, x0 = [dev(g["in_" + k], grad=True) for k in ("C", "c", "F", "f", "x0")]
+    mpc = MPC(n, m, T, u_lower=dev(g["in_u_lower"]), u_upper=dev(g["in_u_upper"]), n_batch=B, verbose=-1,
+              single_qp_solve=True, add_goal_constraint=True,
+              x_goal=torch.zeros(B, n, dtype=torch.float64, device="cuda"))
+    x, u = mpc(x0, QuadCost(C, c), LinDx(F, f), None)
+    np.testing.assert_allclose(x.detach().cpu().numpy(), g["x"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(u.detach().cpu().numpy(), g["u"], rtol=1e-6, atol=1e-8)
+    (x.sum() + 2.0 * u.sum()).backward()
+    for k, t in (("C", C), ("c", c), ("F", F), ("f", f), ("x0", x0)):
+        got = t.grad.cpu().numpy() if t.grad is not None else np.zeros(t.shape)
+        np.testing.assert_allclose(got, g["d" + k], rtol=1e-4, atol=1e-6, err_msg="d" + k)
+
+
 def test_mpc_rollout_consistency_full_batch():
     """B=4096 metric shape: the returned trajectory satisfies the (linear) dynamics and bounds."""
     from diff_qp_mpc_amd.qp_wrapper import MPC, QuadCost, LinDx
