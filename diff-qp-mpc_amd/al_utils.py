@@ -222,7 +222,9 @@ def line_search_newton(update, x_est, meritfnQ, merit, x0):
     x_new = cand[idx, ar]
     status = (best < merit).float()
     keep = status.to(x_est.dtype)[:, None, None]
-    return keep * x_new + (1 - keep) * x_est, best, steps[idx, ar].mean().item(), status
+    # mean accepted step: left on the device (the reference calls .item(), al_utils.py:527, a host
+    # sync per Newton step; NewtonAL ignores the value)
+    return keep * x_new + (1 - keep) * x_est, best, steps[idx, ar].mean(), status
 
 
 class NewtonAL(torch.autograd.Function):
@@ -245,8 +247,10 @@ class NewtonAL(torch.autograd.Function):
             if not chol_failed:
                 upd, L, info = newton_step(terms, grad)
                 update = upd.reshape(B, T, nt).to(x_est.dtype)
-                if bool(torch.isnan(update).any()) or bool(torch.isinf(update).any()):
-                    chol_failed = True             # al_utils.py:419-423
+                # al_utils.py:419-423 scans `update` for NaN/Inf (two reductions + two host syncs);
+                # the kernel reports the same condition per problem in `info` (NaN update <=> info != 0)
+                if bool((info != 0).any()):
+                    chol_failed = True
             if chol_failed:
                 update = -torch.linalg.solve(terms.dense(), grad.reshape(B, -1)).reshape(B, T, nt)
             if ls:
