@@ -38,7 +38,12 @@ DQP_MAX_DIM = 64
 # every symbol include/dqp.h declares
 SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes",
            "dqp_qp_forward", "dqp_qp_backward", "dqp_mpc_assemble", "dqp_mpc_assemble_backward",
-           "dqp_al_newton_step", "dqp_al_chol_solve")
+           "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble")
+
+
+class dqp_al_mpc_dims(ctypes.Structure):
+    _fields_ = [("nbatch", ctypes.c_int32), ("n_state", ctypes.c_int32), ("n_ctrl", ctypes.c_int32),
+                ("T", ctypes.c_int32)]
 
 
 class dqp_al_dims(ctypes.Structure):
@@ -89,6 +94,8 @@ def load():
     lib.dqp_al_newton_step.argtypes = [ctypes.POINTER(dqp_al_dims)] + [_dp] * 8
     lib.dqp_al_chol_solve.restype = ctypes.c_int
     lib.dqp_al_chol_solve.argtypes = [ctypes.POINTER(dqp_al_dims)] + [_dp] * 4
+    lib.dqp_al_assemble.restype = ctypes.c_int
+    lib.dqp_al_assemble.argtypes = [ctypes.POINTER(dqp_al_mpc_dims)] + [_dp] * 8
     _lib = lib
     return lib
 

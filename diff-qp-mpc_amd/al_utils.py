@@ -161,10 +161,39 @@ def merit_grad_hessian(xu, Q, q, dx, dx_jac, x0, lamda, rho, x_lower, x_upper, u
                        diag_cost=True):
     """grad = Q xu + q + J^T lamda + rho Jc^T res_clamp ; Hessian terms (al_utils.py:62-102)."""
     B = xu.shape[0]
-    res, resc, J, Jc = constraint_jacobian(xu, x0, dx_jac, u_lower, u_upper)
-    grad = (compute_cost_gradient(xu, Q, q, diag_cost).reshape(B, -1)
-            + torch.bmm(lamda[:, None], J)[:, 0] + rho * torch.bmm(resc[:, None], Jc)[:, 0])
+    Jc, gterm = assemble_jacobian(xu, x0, dx_jac, lamda, rho, u_lower, u_upper)
+    grad = compute_cost_gradient(xu, Q, q, diag_cost).reshape(B, -1) + gterm.to(xu.dtype)
     return grad, HessianTerms(Jc, Q.reshape(B, -1), rho)
+
+
+def assemble_jacobian(xu, x0, dx_jac, lamda, rho, u_lower, u_upper):
+    """Clamped constraint Jacobian Jc (B,ncon,nz) and J^T lam + rho Jc^T res_c (B,nz) in one
+    launch (dqp_al_assemble) from the per-knot dynamics Jacobians -- the fused form of
+    constraint_jacobian() + the two bmm's the reference does (al_utils.py:62-102,162-318)."""
+    lib = _lib.load()
+    n = x0.shape[-1]
+    B, T, nt = xu.shape
+    m = nt - n
+    x, u = _split(xu, n)
+    x_next, (Jx, Ju) = dx_jac(x[:, :-1].reshape(-1, n), u[:, :-1].reshape(-1, m))
+    eq = torch.cat((x[:, 1:] - x_next.view(B, T - 1, n), x[:, :1] - x0[:, None]), 1).reshape(B, -1)
+    _, iqc = dyn_res_ineq(x, u, x0, None, None, u_lower, u_upper)
+    resc = torch.cat((eq, iqc), 1).detach().double().contiguous()
+    _need_gpu(resc)
+    Jx = Jx.detach().double().reshape(B, T - 1, n, n).contiguous()
+    Ju = Ju.detach().double().reshape(B, T - 1, n, m).contiguous()
+    lam = lamda.detach().double().contiguous()
+    rh = rho.detach().double().reshape(B).contiguous()
+    dev = resc.device
+    ncon, nz = T * n + 2 * T * m, T * nt
+    Jc = torch.empty(B, ncon, nz, dtype=torch.float64, device=dev)
+    gterm = torch.empty(B, nz, dtype=torch.float64, device=dev)
+    dims = _lib.dqp_al_mpc_dims(B, n, m, T)
+    with torch.cuda.device(dev):
+        rc = lib.dqp_al_assemble(ctypes.byref(dims), _ptr(Jx), _ptr(Ju), _ptr(lam), _ptr(resc), _ptr(rh),
+                                 _ptr(Jc), _ptr(gterm), _stream(dev))
+    _lib.check(rc, "dqp_al_assemble")
+    return Jc, gterm
 
 
 # ------------------------------------------------------------------------------------------

@@ -415,6 +415,69 @@ int fill(const dqp_al_dims *d, AlP &P, size_t &lds)
     return DQP_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Constraint Jacobian fill + J^T (lam + rho res_c)  (al_utils.py:62-102,162-318)
+struct AsmP {
+    const double *Jx, *Ju, *lam, *resc, *rho;
+    double *Jc, *gterm;
+    int B, n, m, T;
+};
+
+// value of J[row][col] for one problem; act: inequality rows count only when active
+__device__ __forceinline__ double jac_entry(const AsmP &P, const double *Jx, const double *Ju,
+                                            const double *resc, int row, int col, bool clamp)
+{
+    const int n = P.n, m = P.m, T = P.T, nt = n + m, neq = T * n;
+    const int tc = col / nt, jc = col - tc * nt;
+    if (row < neq) {
+        const int t = row / n, r = row - t * n;
+        if (t == T - 1) return (tc == 0 && jc == r) ? 1.0 : 0.0;                 // x_0 - x0
+        if (tc == t) return jc < n ? -Jx[(t * n + r) * n + jc] : -Ju[(t * n + r) * m + (jc - n)];
+        return (tc == t + 1 && jc == r) ? 1.0 : 0.0;                            // + x_{t+1}
+    }
+    const int q = row - neq, t = q / (2 * m), k = q - t * 2 * m;                 // [upper (m), lower (m)]
+    if (clamp && !(resc[row] > 0.0)) return 0.0;
+    if (tc != t || jc < n) return 0.0;
+    const int i = jc - n;
+    return k < m ? (i == k ? 1.0 : 0.0) : (i == k - m ? -1.0 : 0.0);
+}
+
+__global__ __launch_bounds__(256) void al_assemble_kernel(AsmP P)
+{
+    const int n = P.n, m = P.m, T = P.T, nt = n + m, nz = T * nt, neq = T * n, ncon = neq + 2 * T * m;
+    const long long b = blockIdx.x;
+    const double *Jx = P.Jx + b * (long long)(T - 1) * n * n, *Ju = P.Ju + b * (long long)(T - 1) * n * m;
+    const double *resc = P.resc + b * (long long)ncon;
+    if (P.Jc) {
+        double *Jc = P.Jc + b * (long long)ncon * nz;
+        for (int e = threadIdx.x; e < ncon * nz; e += 256) {
+            const int row = e / nz, col = e - row * nz;
+            Jc[e] = jac_entry(P, Jx, Ju, resc, row, col, true);
+        }
+    }
+    if (P.gterm) {
+        // column sums with mu = lam + rho res_c (for an inactive inequality res_c = 0, so the
+        // clamped and the full Jacobian give the same term): only the structurally non-zero rows
+        const double *lam = P.lam + b * (long long)ncon;
+        const double rho = P.rho[b];
+        for (int col = threadIdx.x; col < nz; col += 256) {
+            const int t = col / nt, j = col - t * nt;
+            auto mu = [&](int row) { return lam[row] + rho * resc[row]; };
+            double acc = 0.0;
+            if (t < T - 1)
+                for (int r = 0; r < n; ++r) acc += jac_entry(P, Jx, Ju, resc, t * n + r, col, false) * mu(t * n + r);
+            if (j < n) {
+                if (t >= 1) acc += mu((t - 1) * n + j);
+                if (t == 0) acc += mu((T - 1) * n + j);
+            } else {
+                const int i = j - n;
+                acc += mu(neq + t * 2 * m + i) - mu(neq + t * 2 * m + m + i);
+            }
+            P.gterm[b * (long long)nz + col] = acc;
+        }
+    }
+}
+
 template <typename K>
 int launch(K kernel, const AlP &P, size_t lds, void *stream, int threads = 256)
 {
@@ -465,6 +528,18 @@ dqp_al_chol_solve(const dqp_al_dims *dims, const double *L, const double *rhs, d
     if (!L || !rhs || !out) return DQP_ERR_BAD_ARG;
     P.Lin = L; P.rhs = rhs; P.out = out;
     return launch(al_chol_solve_kernel, P, lds, stream);
+}
+
+__attribute__((visibility("default"))) int
+dqp_al_assemble(const dqp_al_mpc_dims *d, const double *Jx, const double *Ju, const double *lam,
+                const double *res_c, const double *rho, double *Jc, double *gterm, void *stream)
+{
+    if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2) return DQP_ERR_BAD_ARG;
+    if (d->nbatch == 0) return DQP_OK;
+    if (!Jx || !Ju || !res_c || (gterm && (!lam || !rho))) return DQP_ERR_BAD_ARG;
+    AsmP P = {Jx, Ju, lam, res_c, rho, Jc, gterm, d->nbatch, d->n_state, d->n_ctrl, d->T};
+    hipLaunchKernelGGL(al_assemble_kernel, dim3(P.B), dim3(256), 0, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
 }  // extern "C"

@@ -193,6 +193,29 @@ int dqp_al_newton_step(const dqp_al_dims *dims, const double *Jc, const double *
 int dqp_al_chol_solve(const dqp_al_dims *dims, const double *L, const double *rhs, double *out,
                       void *stream);
 
+/*
+ * Replaces the Jacobian fill of al_utils.constraint_res_jac2 / dyn_res_eq_jac / dyn_res_ineq_jac
+ * (qpth/al_utils.py:162-318: vmap(block_diag), zero-fills, index scatters, the active-set mask)
+ * and the two bmm's J^T lam + rho Jc^T res_c of merit_grad_hessian (al_utils.py:62-102).
+ * Inputs: the per-knot dynamics Jacobians Jx (B,T-1,n,n) = df/dx_t and Ju (B,T-1,n,m) = df/du_t,
+ * lam (B,ncon), res_c (B,ncon) = the residual with inactive inequalities clamped to 0, rho (B).
+ * Row order: (T-1) n dynamics rows x_{t+1} - f(x_t,u_t) knot-major, n rows x_0 - x0, then per
+ * knot [u - u_upper (m), u_lower - u (m)]; columns per knot [x_t (n), u_t (m)];
+ * ncon = T n + 2 T m, nz = T (n + m).
+ * Outputs: Jc (B,ncon,nz) with the rows of inactive inequalities (res_c <= 0) zeroed (every
+ * element written exactly once), gterm (B,nz) = J^T lam + rho Jc^T res_c.  Either may be NULL.
+ */
+typedef struct dqp_al_mpc_dims {
+    int32_t nbatch;
+    int32_t n_state;
+    int32_t n_ctrl;
+    int32_t T;
+} dqp_al_mpc_dims;
+
+int dqp_al_assemble(const dqp_al_mpc_dims *dims, const double *Jx, const double *Ju,
+                    const double *lam, const double *res_c, const double *rho, double *Jc,
+                    double *gterm, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

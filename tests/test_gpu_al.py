@@ -102,6 +102,27 @@ def test_newton_step_reports_indefinite_hessian():
     assert np.isnan(u[1]).all() and np.allclose(u[0], -1.0) and np.allclose(u[2], -1.0)
 
 
+@pytest.mark.parametrize("B,T", [(5, 4), (33, 20), (1, 2)])
+def test_assemble_jacobian_kernel(B, T):
+    """dqp_al_assemble vs the index-scatter construction of al_utils.py:162-318 (restated in torch
+    in al_utils.constraint_jacobian and in numpy in oracle/al_oracle.py) and the two bmm's of
+    merit_grad_hessian: exact for Jc (copies and +-1), 1e-12 for the products."""
+    from diff_qp_mpc_amd import al_utils
+    gen = torch.Generator().manual_seed(T)
+    n, m = 2, 1
+    xu = torch.randn(B, T, n + m, generator=gen, dtype=torch.float64).cuda()
+    x0 = torch.randn(B, n, generator=gen, dtype=torch.float64).cuda()
+    lam = torch.randn(B, T * n + 2 * T * m, generator=gen, dtype=torch.float64).cuda()
+    rho = (10.0 ** torch.randint(0, 3, (B, 1), generator=gen).double()).cuda()
+    lo, hi = torch.full((m,), -0.5, dtype=torch.float64).cuda(), torch.full((m,), 0.5, dtype=torch.float64).cuda()
+    res, resc, J, Jc_ref = al_utils.constraint_jacobian(xu, x0, PendulumJac(), lo, hi)
+    g_ref = torch.bmm(lam[:, None], J)[:, 0] + rho * torch.bmm(resc[:, None], Jc_ref)[:, 0]
+    Jc, gterm = al_utils.assemble_jacobian(xu, x0, PendulumJac(), lam, rho, lo, hi)
+    assert torch.equal(Jc, Jc_ref)
+    np.testing.assert_allclose(gterm.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-12, atol=1e-12)
+    assert int((resc[:, T * n:] > 0).sum()) > 0 or B == 1            # some inequalities active
+
+
 @pytest.mark.parametrize("name", AL_CASES)
 def test_al_mpc_two_calls_vs_reference(name):
     from diff_qp_mpc_amd import AL_mpc, al_utils
