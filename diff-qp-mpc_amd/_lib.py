@@ -38,7 +38,7 @@ DQP_MAX_DIM = 64
 # every symbol include/dqp.h declares
 SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes",
            "dqp_qp_forward", "dqp_qp_backward", "dqp_mpc_assemble", "dqp_mpc_assemble_backward",
-           "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble")
+           "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble", "dqp_al_merit")
 
 
 class dqp_al_mpc_dims(ctypes.Structure):
@@ -96,6 +96,8 @@ def load():
     lib.dqp_al_chol_solve.argtypes = [ctypes.POINTER(dqp_al_dims)] + [_dp] * 4
     lib.dqp_al_assemble.restype = ctypes.c_int
     lib.dqp_al_assemble.argtypes = [ctypes.POINTER(dqp_al_mpc_dims)] + [_dp] * 8
+    lib.dqp_al_merit.restype = ctypes.c_int
+    lib.dqp_al_merit.argtypes = [ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int32] + [_dp] * 11
     _lib = lib
     return lib
 

@@ -138,6 +138,9 @@ def compute_cost_gradient(xu, Q, q, diag_cost=True):
 def merit_function(xu, Q, q, dx, x0, lamda, rho, x_lower, x_upper, u_lower, u_upper, diag_cost=True):
     """cost + rho/2 |res_clamp|^2 + lamda . res; a leading candidate axis (n_ls,B,T,nt) is
     folded into the batch (al_utils.py:37-59)."""
+    if (xu.is_cuda and not torch.is_grad_enabled() and torch.is_tensor(u_lower) and u_lower.dim() == 1
+            and x_lower is None and x_upper is None):
+        return _merit_fused(xu, Q, q, dx, x0, lamda, rho, u_lower, u_upper)
     if xu.dim() == 4:
         k, B = xu.shape[:2]
         rep = lambda t: t[None].expand(k, *t.shape).reshape(k * B, *t.shape[1:])
@@ -145,6 +148,32 @@ def merit_function(xu, Q, q, dx, x0, lamda, rho, x_lower, x_upper, u_lower, u_up
     B = xu.shape[0]
     res, resc = dyn_res(xu, dx, x0, x_lower, x_upper, u_lower, u_upper)
     return compute_cost(xu, Q, q) + 0.5 * rho[:, 0] * (resc * resc).sum(1) + (lamda * res).sum(1)
+
+
+def _merit_fused(xu, Q, q, dx, x0, lamda, rho, u_lower, u_upper):
+    """merit_function through dqp_al_merit: the dynamics are evaluated by the caller's module (one
+    batched call over all candidates), cost + penalty + multiplier terms in one launch."""
+    lib = _lib.load()
+    cand = xu.dim() == 4
+    k = xu.shape[0] if cand else 1
+    flat = xu.reshape(-1, *xu.shape[-2:])
+    n = x0.shape[-1]
+    B, T, nt = x0.shape[0], flat.shape[1], flat.shape[2]
+    m = nt - n
+    x, u = _split(flat, n)
+    if isinstance(dx, LinDx) and k > 1:     # F, f are per problem (time-major): tile over the candidates
+        dx = LinDx(dx.F.repeat(1, k, 1, 1), dx.f.repeat(1, k, 1))
+    x_next = _step(dx, x, u)
+    d64 = lambda t: t.detach().double().contiguous()
+    xu64, xn64 = d64(flat), d64(x_next)
+    merit = torch.empty(k * B, dtype=torch.float64, device=xu.device)
+    dims = _lib.dqp_al_mpc_dims(B, n, m, T)
+    with torch.cuda.device(xu.device):
+        rc = lib.dqp_al_merit(ctypes.byref(dims), k, _ptr(xu64), _ptr(xn64), _ptr(d64(x0)), _ptr(d64(Q)),
+                              _ptr(d64(q)), _ptr(d64(lamda)), _ptr(d64(rho).reshape(B)), _ptr(d64(u_lower)),
+                              _ptr(d64(u_upper)), _ptr(merit), _stream(xu.device))
+    _lib.check(rc, "dqp_al_merit")
+    return merit.to(xu.dtype)
 
 
 class HessianTerms:

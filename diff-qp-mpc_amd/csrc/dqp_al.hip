@@ -21,6 +21,7 @@
 #include <stdint.h>
 
 #include "../../include/dqp.h"
+#include "dqp_r16_prims.h"   // row_sum (DPP row reduction)
 
 namespace dqp { extern unsigned long long *g_debug_stamps; }
 
@@ -478,6 +479,49 @@ __global__ __launch_bounds__(256) void al_assemble_kernel(AsmP P)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// merit function of a batch of candidate trajectories (al_utils.py:37-59); 16 lanes per
+// (candidate, problem): lane j of the group sweeps knots j, j+16, ... and the partial sums are
+// combined with DPP row reductions
+struct MeritP {
+    const double *xu, *xn, *x0, *Qd, *q, *lam, *rho, *ul, *uu;
+    double *merit;
+    int B, n, m, T, ncand;
+};
+
+__global__ __launch_bounds__(256) void al_merit_kernel(MeritP P)
+{
+    const int n = P.n, m = P.m, T = P.T, nt = n + m, neq = T * n, ncon = neq + 2 * T * m;
+    const long long item = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);      // (cand, problem)
+    const int r = threadIdx.x & 15;
+    const long long total = (long long)P.ncand * P.B;
+    const long long it = item < total ? item : total - 1;
+    const long long b = it % P.B;
+    const double *xu = P.xu + it * (long long)T * nt, *xn = P.xn + it * (long long)(T - 1) * n;
+    const double *Qd = P.Qd + b * (long long)T * nt, *q = P.q + b * (long long)T * nt;
+    const double *lam = P.lam + b * (long long)ncon, *x0 = P.x0 + b * (long long)n;
+    const double rho = P.rho[b];
+    double acc = 0.0;
+    for (int t = r; t < T; t += 16) {
+        const double *z = xu + t * nt;
+        for (int j = 0; j < nt; ++j) acc += (0.5 * Qd[t * nt + j] * z[j] + q[t * nt + j]) * z[j];
+        for (int j = 0; j < n; ++j) {                       // equality row block of knot t
+            double res;
+            int row;
+            if (t < T - 1) { res = xu[(t + 1) * nt + j] - xn[t * n + j]; row = t * n + j; }
+            else { res = xu[j] - x0[j]; row = (T - 1) * n + j; }
+            acc += (0.5 * rho * res + lam[row]) * res;
+        }
+        for (int i = 0; i < m; ++i) {                       // box rows of knot t
+            const double u = z[n + i], up = u - P.uu[i], lo = P.ul[i] - u;
+            const int row = neq + t * 2 * m + i;
+            acc += lam[row] * up + lam[row + m] * lo + 0.5 * rho * (fmax(up, 0.0) * fmax(up, 0.0) + fmax(lo, 0.0) * fmax(lo, 0.0));
+        }
+    }
+    acc = dqp::r16::row_sum(acc);
+    if (r == 0 && item < total) P.merit[item] = acc;
+}
+
 template <typename K>
 int launch(K kernel, const AlP &P, size_t lds, void *stream, int threads = 256)
 {
@@ -539,6 +583,22 @@ dqp_al_assemble(const dqp_al_mpc_dims *d, const double *Jx, const double *Ju, co
     if (!Jx || !Ju || !res_c || (gterm && (!lam || !rho))) return DQP_ERR_BAD_ARG;
     AsmP P = {Jx, Ju, lam, res_c, rho, Jc, gterm, d->nbatch, d->n_state, d->n_ctrl, d->T};
     hipLaunchKernelGGL(al_assemble_kernel, dim3(P.B), dim3(256), 0, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+__attribute__((visibility("default"))) int
+dqp_al_merit(const dqp_al_mpc_dims *d, int32_t ncand, const double *xu, const double *x_next,
+             const double *x0, const double *Qdiag, const double *q, const double *lam,
+             const double *rho, const double *u_lower, const double *u_upper, double *merit, void *stream)
+{
+    if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2 || ncand < 0) return DQP_ERR_BAD_ARG;
+    if (d->nbatch == 0 || ncand == 0) return DQP_OK;
+    if (!xu || !x_next || !x0 || !Qdiag || !q || !lam || !rho || !u_lower || !u_upper || !merit)
+        return DQP_ERR_BAD_ARG;
+    MeritP P = {xu, x_next, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, d->nbatch, d->n_state,
+                d->n_ctrl, d->T, ncand};
+    const long long total = (long long)ncand * d->nbatch;
+    hipLaunchKernelGGL(al_merit_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 

@@ -216,6 +216,21 @@ int dqp_al_assemble(const dqp_al_mpc_dims *dims, const double *Jx, const double 
                     const double *lam, const double *res_c, const double *rho, double *Jc,
                     double *gterm, void *stream);
 
+/*
+ * Replaces al_utils.merit_function (qpth/al_utils.py:37-59) after the dynamics have been
+ * evaluated:  merit = sum (1/2 Q xu^2 + q xu) + rho/2 |res_c|^2 + lam . res  with res the
+ * residual vector in dqp_al_assemble's row order (x_{t+1} - x_next_t, x_0 - x0, u - u_upper,
+ * u_lower - u) and res_c its clamped form.  ncand candidate trajectories per problem (the
+ * 20-way line search of line_search_newton, al_utils.py:503-527, evaluates them as one batch)
+ * share the problem's x0, Qdiag, q, lam, rho: xu (ncand,B,T,n+m), x_next (ncand,B,T-1,n) =
+ * f(x_t,u_t) for the first T-1 knots, x0 (B,n), Qdiag/q (B,T,n+m), lam (B,ncon), rho (B),
+ * u_lower/u_upper (m).  Output merit (ncand,B).
+ */
+int dqp_al_merit(const dqp_al_mpc_dims *dims, int32_t ncand, const double *xu, const double *x_next,
+                 const double *x0, const double *Qdiag, const double *q, const double *lam,
+                 const double *rho, const double *u_lower, const double *u_upper, double *merit,
+                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

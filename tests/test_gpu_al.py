@@ -123,6 +123,28 @@ def test_assemble_jacobian_kernel(B, T):
     assert int((resc[:, T * n:] > 0).sum()) > 0 or B == 1            # some inequalities active
 
 
+@pytest.mark.parametrize("B,T,k", [(5, 4, 1), (33, 20, 20), (2, 35, 3)])
+def test_merit_kernel(B, T, k):
+    """dqp_al_merit vs the torch restatement of al_utils.merit_function (al_utils.py:37-59), with
+    and without a leading candidate axis (the 20-way line search)."""
+    from diff_qp_mpc_amd import al_utils
+    gen = torch.Generator().manual_seed(T + k)
+    n, m = 2, 1
+    shape = (k, B, T, n + m) if k > 1 else (B, T, n + m)
+    xu = torch.randn(*shape, generator=gen, dtype=torch.float64).cuda()
+    x0 = torch.randn(B, n, generator=gen, dtype=torch.float64).cuda()
+    Q = (torch.rand(B, T, n + m, generator=gen, dtype=torch.float64) + 0.1).cuda()
+    q = torch.randn(B, T, n + m, generator=gen, dtype=torch.float64).cuda()
+    lam = torch.randn(B, T * n + 2 * T * m, generator=gen, dtype=torch.float64).cuda()
+    rho = (10.0 ** torch.randint(0, 3, (B, 1), generator=gen).double()).cuda()
+    lo, hi = torch.full((m,), -0.5, dtype=torch.float64).cuda(), torch.full((m,), 0.5, dtype=torch.float64).cuda()
+    with torch.no_grad():
+        got = al_utils.merit_function(xu, Q, q, Pendulum(), x0, lam, rho, None, None, lo, hi)
+    with torch.enable_grad():          # grad mode on -> the torch path
+        want = al_utils.merit_function(xu, Q, q, Pendulum(), x0, lam, rho, None, None, lo, hi)
+    np.testing.assert_allclose(got.cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-12, atol=1e-10)
+
+
 @pytest.mark.parametrize("name", AL_CASES)
 def test_al_mpc_two_calls_vs_reference(name):
     from diff_qp_mpc_amd import AL_mpc, al_utils
