@@ -10,9 +10,9 @@ What runs where:
   * dense QP assembly (compute_Qq/Ab/Gh_dense, qp_wrapper.py:638-679) and its adjoint: HIP
     kernels behind dqp_mpc_assemble / dqp_mpc_assemble_backward (csrc/dqp_mpc.hip);
   * the QP itself (qp.DenseQPFunction, qp_wrapper.py:316): fused HIP PDIPM (csrc/dqp_*.hip);
-  * the SQP outer loop, rollout, cost and line search (qp_wrapper.py:298-436, 598-611, 690-692):
-    torch ops on the same device, statement-for-statement the reference's control flow
-    (they call user-supplied Python dynamics, which cannot be fused).
+  * the SQP outer loop, rollout, cost and line search (behaviour of qp_wrapper.py:298-436,
+    598-611, 690-692): vectorised torch ops on the same device (they call user-supplied Python
+    dynamics, which cannot be fused).
 
 Difference from the reference: it passes the TRUE-dynamics residual closure into the PDIPM
 (`dyn_res_lam`, qp_wrapper.py:309,316); the fused kernel evaluates the residual of the
@@ -20,9 +20,8 @@ LINEARISED dynamics, A z - b.  For LinDx the two are identical (this is what the
 pin); for nonlinear dynamics they differ inside the QP iterations only.
 """
 import ctypes
-import sys
-from collections import namedtuple
 from enum import Enum
+from typing import NamedTuple, Optional
 
 import torch
 from torch.autograd import Function
@@ -31,29 +30,33 @@ from torch.nn import Module
 from . import _lib
 from .qp import DenseQPFunction
 
-QuadCost = namedtuple('QuadCost', 'C c')
-LinDx = namedtuple('LinDx', 'F f')
-QuadCost.__new__.__defaults__ = (None,) * len(QuadCost._fields)
-LinDx.__new__.__defaults__ = (None,) * len(LinDx._fields)
+
+class QuadCost(NamedTuple):
+    """Quadratic stage cost 1/2 tau^T C tau + c^T tau (same fields as the reference's type)."""
+    C: Optional[torch.Tensor] = None
+    c: Optional[torch.Tensor] = None
 
 
-class GradMethods(Enum):
-    AUTO_DIFF = 1
-    FINITE_DIFF = 2
-    ANALYTIC = 3
-    ANALYTIC_CHECK = 4
+class LinDx(NamedTuple):
+    """Affine dynamics x_{t+1} = F_t [x_t; u_t] + f_t (same fields as the reference's type)."""
+    F: Optional[torch.Tensor] = None
+    f: Optional[torch.Tensor] = None
+
+
+# member names and values as in qpth.qp_wrapper.GradMethods
+GradMethods = Enum("GradMethods", ["AUTO_DIFF", "FINITE_DIFF", "ANALYTIC", "ANALYTIC_CHECK"])
 
 
 def detach_maybe(x):
-    """qpth/util.py:204-207"""
-    if x is None:
-        return None
-    return x if not x.requires_grad else x.detach()
+    """None stays None; tensors that track gradients are detached."""
+    if x is None or not x.requires_grad:
+        return x
+    return x.detach()
 
 
 def bmv(X, y):
-    """qpth/util.py:92-93"""
-    return X.bmm(y.unsqueeze(2)).squeeze(2)
+    """Batched matrix-vector product (B,r,c) x (B,c) -> (B,r)."""
+    return torch.matmul(X, y[..., None])[..., 0]
 
 
 def _ptr(t):
@@ -136,102 +139,83 @@ class MPC(Module):
                  detach_unconverged=True, backprop=True, slew_rate_penalty=None, prev_ctrl=None,
                  not_improved_lim=5, best_cost_eps=1e-4, solver_type='dense',
                  single_qp_solve=False, add_goal_constraint=False, x_goal=None):
+        given = dict(locals())
         super().__init__()
-        assert (u_lower is None) == (u_upper is None)
-        assert max_linesearch_iter > 0
+        if (u_lower is None) != (u_upper is None):
+            raise AssertionError("give both control bounds or neither")
+        if max_linesearch_iter <= 0:
+            raise AssertionError("max_linesearch_iter must be positive")
         if solver_type != 'dense':
             raise NotImplementedError("only solver_type='dense' exists in the reference too")
-        self.n_state, self.n_ctrl, self.T = n_state, n_ctrl, T
-        self.u_lower, self.u_upper, self.x_goal = u_lower, u_upper, x_goal
-        if not isinstance(u_lower, float):
-            self.u_lower = detach_maybe(self.u_lower)
-        if not isinstance(u_upper, float):
-            self.u_upper = detach_maybe(self.u_upper)
-        self.u_zero_I = detach_maybe(u_zero_I)
-        self.u_init = detach_maybe(u_init)
-        self.x_init = detach_maybe(x_init)
-        self.qp_iter = qp_iter
-        self.grad_method = grad_method
-        self.delta_u = delta_u
-        self.verbose = verbose
-        self.eps = eps
-        self.back_eps = back_eps
-        self.n_batch = n_batch
-        self.linesearch_decay = linesearch_decay
-        self.max_linesearch_iter = max_linesearch_iter
-        self.exit_unconverged = exit_unconverged
-        self.detach_unconverged = detach_unconverged
-        self.backprop = backprop
-        self.not_improved_lim = not_improved_lim
-        self.best_cost_eps = best_cost_eps
-        self.slew_rate_penalty = slew_rate_penalty
-        self.prev_ctrl = prev_ctrl
-        self.solver_type = solver_type
-        self.single_qp_solve = single_qp_solve
-        self.add_goal_constraint = add_goal_constraint
+        # every option is kept under the reference's attribute name; tensors that arrive with a
+        # graph attached are detached (bounds may also be plain floats)
+        plain = ("n_state", "n_ctrl", "T", "qp_iter", "grad_method", "delta_u", "verbose", "eps",
+                 "back_eps", "n_batch", "linesearch_decay", "max_linesearch_iter", "exit_unconverged",
+                 "detach_unconverged", "backprop", "slew_rate_penalty", "prev_ctrl", "not_improved_lim",
+                 "best_cost_eps", "solver_type", "single_qp_solve", "add_goal_constraint", "x_goal")
+        for name in plain:
+            setattr(self, name, given[name])
+        for name in ("u_lower", "u_upper", "u_zero_I", "u_init", "x_init"):
+            v = given[name]
+            setattr(self, name, v if isinstance(v, float) else detach_maybe(v))
 
-    # ------------------------------------------------------------------ qp_wrapper.py:213-296
+    # ------------------------------------------------------------------ behaviour of qp_wrapper.py:213-296
+    def _time_major(self, t, full_rank, n_batch, what):
+        """Broadcast a (…)-shaped cost / initial-guess tensor to its time-major batched form
+        (T, B, …): tensors lacking the batch axis, or both the time and batch axes, are expanded."""
+        missing = full_rank - t.dim()
+        if missing == 2:
+            t = t[None, None].expand(self.T, n_batch, *t.shape)
+        elif missing == 1:
+            t = t[:, None].expand(t.shape[0], n_batch, *t.shape[1:])
+        if t.dim() != full_rank:
+            raise SystemExit("MPC Error: Unexpected %s shape." % what)
+        return t
+
     def forward(self, x0, cost, dx, dx_jac, dx_true=None):
-        self.dx_true = dx if dx_true is None else dx_true
-        assert isinstance(cost, QuadCost) or isinstance(cost, Module) or isinstance(cost, Function)
-        if self.n_batch is not None:
-            n_batch = self.n_batch
-        elif isinstance(cost, QuadCost) and cost.C.ndimension() == 4:
-            n_batch = cost.C.size(1)
-        else:
-            print('MPC Error: Could not infer batch size, pass in as n_batch')
-            sys.exit(-1)
-        self.n_batch = n_batch      # the reference reads self.n_batch in single_qp/dyn_res
-
+        self.dx_true = dx_true if dx_true is not None else dx
+        if not isinstance(cost, (QuadCost, Module, Function)):
+            raise AssertionError("cost must be a QuadCost (or a module)")
+        n_batch = self.n_batch
+        if n_batch is None:
+            if not (isinstance(cost, QuadCost) and cost.C.dim() == 4):
+                raise SystemExit('MPC Error: Could not infer batch size, pass in as n_batch')
+            n_batch = cost.C.shape[1]
+        self.n_batch = n_batch
         if isinstance(cost, QuadCost):
-            C, c = cost
-            if C.ndimension() == 2:
-                C = C.unsqueeze(0).unsqueeze(0).expand(self.T, n_batch, self.n_state + self.n_ctrl, -1)
-            elif C.ndimension() == 3:
-                C = C.unsqueeze(1).expand(self.T, n_batch, self.n_state + self.n_ctrl, -1)
-            if c.ndimension() == 1:
-                c = c.unsqueeze(0).unsqueeze(0).expand(self.T, n_batch, -1)
-            elif c.ndimension() == 2:
-                c = c.unsqueeze(1).expand(self.T, n_batch, -1)
-            if C.ndimension() != 4 or c.ndimension() != 3:
-                print('MPC Error: Unexpected QuadCost shape.')
-                sys.exit(-1)
-            cost = QuadCost(C, c)
+            cost = QuadCost(self._time_major(cost.C, 4, n_batch, "QuadCost"),
+                            self._time_major(cost.c, 3, n_batch, "QuadCost"))
+        if x0.dim() != 2 or x0.shape[0] != n_batch:
+            raise AssertionError("x0 must be (n_batch, n_state)")
 
-        assert x0.ndimension() == 2 and x0.size(0) == n_batch
-        if self.u_init is None:
-            u = torch.zeros(self.T, n_batch, self.n_ctrl, dtype=x0.dtype, device=x0.device)   # on device:
-            # the reference builds it on the host and copies (qp_wrapper.py:174), a blocking H2D per call
-        else:
-            u = self.u_init
-            if u.ndimension() == 2:
-                u = u.unsqueeze(1).expand(self.T, n_batch, -1).clone()
-        u = u.type_as(x0.data)
-        if self.x_init is None:
+        def initial(guess, width):
+            if guess is None:
+                return None
+            if guess.dim() == 2:                       # (T, width): shared by the batch
+                guess = guess[:, None].expand(self.T, n_batch, width).clone()
+            return guess.to(dtype=x0.dtype, device=x0.device)
+
+        u = initial(self.u_init, self.n_ctrl)
+        if u is None:       # built on the device (the reference's host-side zeros + copy is a blocking H2D)
+            u = torch.zeros(self.T, n_batch, self.n_ctrl, dtype=x0.dtype, device=x0.device)
+        x = initial(self.x_init, self.n_state)
+        if x is None:
             x = self.rollout(x0, u, dx)
-        else:
-            x = self.x_init
-            if x.ndimension() == 2:
-                x = x.unsqueeze(1).expand(self.T, n_batch, -1).clone()
-        x = x.type_as(x0.data)
+        solve = self.single_qp_ls if self.single_qp_solve else self.solve_nonlin
+        x, u, _ = solve(x, u, dx, dx_jac, x0, cost)
+        return x, u
 
-        if self.single_qp_solve:
-            x, u, cost_total = self.single_qp_ls(x, u, dx, dx_jac, x0, cost)
-        else:
-            x, u, cost_total = self.solve_nonlin(x, u, dx, dx_jac, x0, cost)
-        return (x, u)
-
-    # ------------------------------------------------------------------ qp_wrapper.py:298-324
+    # ------------------------------------------------------------------ behaviour of qp_wrapper.py:298-324
     def single_qp(self, x, u, dx, dx_jac, x0, cost):
+        """One QP around (x, u): returns the step (dx, du) to the QP solution and its cost."""
         if isinstance(dx, LinDx):
-            F, f = dx.F, dx.f
-            if f is None:
-                f = torch.zeros((self.T - 1, self.n_batch, self.n_state), dtype=x0.dtype, device=x0.device)
+            F = dx.F
+            f = dx.f if dx.f is not None else torch.zeros(self.T - 1, self.n_batch, self.n_state,
+                                                          dtype=x0.dtype, device=x0.device)
         else:
             F, f = self.linearize_dynamics(x, detach_maybe(u), dx, dx_jac, diff=False)
-        bounds = self.u_upper is not None
         ul = uu = None
-        if bounds:
+        if self.u_upper is not None:
             as_t = lambda v: (torch.full((self.n_ctrl,), float(v), dtype=torch.float64, device=x0.device)
                               if isinstance(v, float) else v.to(x0.device))
             ul, uu = as_t(self.u_lower), as_t(self.u_upper)
@@ -246,115 +230,106 @@ class MPC(Module):
             Ag[:, ar, (self.T - 1) * nt + ar] = 1.0
             A = torch.cat([A, Ag], 1)
             b = torch.cat([b, torch.zeros(self.n_batch, n, dtype=b.dtype, device=b.device)], 1)
-        xhats_qpf = DenseQPFunction()(Q, q, G, h, A, b, None).to(x0.dtype)
-        xhats_qpf = xhats_qpf.reshape(self.n_batch, self.T, -1)
-        x_hat = xhats_qpf[:, :, :self.n_state].transpose(0, 1)
-        u_hat = xhats_qpf[:, :, self.n_state:].transpose(0, 1)
-        cost_total = self.compute_cost(xhats_qpf, cost)
-        return x_hat - x, u_hat - u, cost_total
+        tau = DenseQPFunction()(Q, q, G, h, A, b, None).to(x0.dtype).reshape(self.n_batch, self.T, -1)
+        x_qp, u_qp = tau[..., :self.n_state].transpose(0, 1), tau[..., self.n_state:].transpose(0, 1)
+        return x_qp - x, u_qp - u, self.compute_cost(tau, cost)
 
-    # ------------------------------------------------------------------ qp_wrapper.py:348-414
+    def _damped_step(self, x, u, dx, dx_jac, x0, cost):
+        """QP step at (x, u) scaled by the line-search factor (the differentiable last step)."""
+        step_x, step_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost)
+        with torch.no_grad():
+            _, _, alpha, cost_total = self.line_search(x, u, step_x, step_u, dx, x0, cost)
+        return x + alpha * step_x, u + alpha * step_u, cost_total
+
+    # ------------------------------------------------------------------ behaviour of qp_wrapper.py:348-414
     def solve_nonlin(self, x, u, dx, dx_jac, x0, cost):
-        best = None
-        n_not_improved = 0
+        """SQP: up to qp_iter gradient-free QP + line-search rounds keeping, per sample, the best
+        trajectory seen (cost within best_cost_eps counts as an improvement), then one
+        differentiable step from that trajectory."""
+        keep_x = keep_u = keep_cost = None
+        stalls = 0          # the reference never increments this counter either (qp_wrapper.py:356-380)
         with torch.no_grad():
-            for i in range(self.qp_iter):
-                u_prev = u.clone()
-                delta_x, delta_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost)
-                x, u, alpha, cost_total = self.line_search(x, u, delta_x, delta_u, dx, x0, cost)
-                full_du_norm = (u - u_prev).norm()
-                if best is None:
-                    best = {'x': x.clone(), 'u': u.clone(), 'costs': cost_total.clone()}
+            for _ in range(self.qp_iter):
+                u_before = u
+                step_x, step_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost)
+                x, u, _, cost_now = self.line_search(x, u, step_x, step_u, dx, x0, cost)
+                if keep_cost is None:
+                    keep_x, keep_u, keep_cost = x.clone(), u.clone(), cost_now.clone()
                 else:
-                    # per-sample best (the reference loops over the batch in Python,
-                    # qp_wrapper.py:372-377; same selection, vectorised)
-                    I = cost_total <= best['costs'] + self.best_cost_eps
-                    if bool(I.any()):
-                        n_not_improved = 0
-                    best['x'][:, I] = x[:, I]
-                    best['u'][:, I] = u[:, I]
-                    best['costs'][I] = cost_total[I]
-                if full_du_norm < self.eps or n_not_improved > self.not_improved_lim:
+                    better = cost_now <= keep_cost + self.best_cost_eps
+                    if bool(better.any()):
+                        stalls = 0
+                    sel = better[None, :, None]
+                    keep_x, keep_u = torch.where(sel, x, keep_x), torch.where(sel, u, keep_u)
+                    keep_cost = torch.where(better, cost_now, keep_cost)
+                if (u - u_before).norm() < self.eps or stalls > self.not_improved_lim:
                     break
-        x, u = best['x'], best['u']
-        delta_x, delta_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost)
-        with torch.no_grad():
-            _, _, alpha, cost_total = self.line_search(x, u, delta_x, delta_u, dx, x0, cost)
-        x = x + delta_x * alpha
-        u = u + delta_u * alpha
-        return x, u, cost_total
+        return self._damped_step(keep_x, keep_u, dx, dx_jac, x0, cost)
 
     def single_qp_ls(self, x, u, dx, dx_jac, x0, cost):
-        delta_x, delta_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost)
-        with torch.no_grad():
-            _, _, alpha, cost_total = self.line_search(x, u, delta_x, delta_u, dx, x0, cost)
-        x = x + delta_x * alpha
-        u = u + delta_u * alpha
-        return x, u, cost_total
+        return self._damped_step(x, u, dx, dx_jac, x0, cost)
 
-    # ------------------------------------------------------------------ qp_wrapper.py:417-436
+    # ------------------------------------------------------------------ behaviour of qp_wrapper.py:417-436
     def line_search(self, x, u, delta_x, delta_u, dx, x0, cost):
-        alpha = torch.ones([1, self.n_batch, 1], dtype=x0.dtype, device=x0.device)
-        cost_total = self.compute_cost(torch.cat((x, u), dim=2).transpose(0, 1), cost)
-        for j in range(self.max_linesearch_iter):
-            u_new = u + delta_u * alpha
-            x_new = self.rollout(x0, u_new, dx)
-            xhats_qpf = torch.cat((x_new, u_new), dim=2).transpose(0, 1)
-            cost_total_new = self.compute_cost(xhats_qpf, cost)
-            if (cost_total_new < cost_total).all():
+        """Backtracking on the true rollout cost: samples whose cost did not drop get their step
+        factor multiplied by linesearch_decay; stops when every sample improved (or after
+        max_linesearch_iter rounds).  Returns the last trial (x, u), the factors and its costs."""
+        alpha = x0.new_ones(1, self.n_batch, 1)
+        cost_here = self.compute_cost(torch.cat((x, u), dim=2).transpose(0, 1), cost)
+        for _ in range(self.max_linesearch_iter):
+            u_try = u + alpha * delta_u
+            x_try = self.rollout(x0, u_try, dx)
+            cost_try = self.compute_cost(torch.cat((x_try, u_try), dim=2).transpose(0, 1), cost)
+            worse = cost_try >= cost_here
+            if not bool(worse.any()):
                 break
-            else:
-                mask = (cost_total_new >= cost_total).to(alpha.dtype)[None, :, None]
-                alpha = alpha * self.linesearch_decay * mask + (1 - mask) * alpha
-        return x_new, u_new, alpha, cost_total_new
+            alpha = torch.where(worse[None, :, None], alpha * self.linesearch_decay, alpha)
+        return x_try, u_try, alpha, cost_try
 
-    # ------------------------------------------------------------------ qp_wrapper.py:481-515
+    # ------------------------------------------------------------------ behaviour of qp_wrapper.py:481-515
     def linearize_dynamics(self, x, u, dynamics, dx_jac, diff):
+        """First-order model of `dynamics` along (x, u): F_t = [df/dx, df/du], f_t = f(x_t,u_t) - F_t tau_t."""
         if self.grad_method != GradMethods.ANALYTIC:
             raise NotImplementedError("only GradMethods.ANALYTIC (dx_jac) is mirrored")
-        n_batch = x[0].size(0)
-        _u = u[:-1].reshape(-1, self.n_ctrl)
-        _x = x[:-1].contiguous().view(-1, self.n_state)
-        _new_x = dynamics(_x, _u)
+        n_batch = x.shape[1]
+        xs = x[:-1].reshape(-1, self.n_state)
+        us = u[:-1].reshape(-1, self.n_ctrl)
+        nxt = dynamics(xs, us)
         if not diff:
-            _new_x, _x, _u = _new_x.detach(), _x.detach(), _u.detach()
-        R, S = dx_jac(_x, _u)[1]
-        f = _new_x - bmv(R, _x) - bmv(S, _u)
-        f = f.view(self.T - 1, n_batch, self.n_state)
-        R = R.contiguous().view(self.T - 1, n_batch, self.n_state, self.n_state)
-        S = S.contiguous().view(self.T - 1, n_batch, self.n_state, self.n_ctrl)
-        F = torch.cat((R, S), 3)
-        return F, f
+            nxt, xs, us = nxt.detach(), xs.detach(), us.detach()
+        fx, fu = dx_jac(xs, us)[1]
+        F = torch.cat((fx, fu), dim=2)
+        f = nxt - bmv(F, torch.cat((xs, us), dim=1))
+        return (F.reshape(self.T - 1, n_batch, self.n_state, self.n_state + self.n_ctrl),
+                f.reshape(self.T - 1, n_batch, self.n_state))
 
-    # ------------------------------------------------------------------ qp_wrapper.py:598-611
+    # ------------------------------------------------------------------ behaviour of qp_wrapper.py:598-611
     def rollout(self, x, actions, dynamics):
-        x = [x]
+        """States (T,B,n) reached from x under `actions` (T,B,m); the last action is unused."""
+        states = [x]
+        linear = isinstance(dynamics, LinDx)
         for t in range(self.T - 1):
-            xt, ut = x[t], actions[t]
-            if isinstance(dynamics, LinDx):
-                new_x = bmv(dynamics.F[t], torch.cat([xt, ut], dim=-1)) + dynamics.f[t]
+            if linear:
+                states.append(bmv(dynamics.F[t], torch.cat((states[-1], actions[t]), dim=-1)) + dynamics.f[t])
             else:
-                new_x = dynamics(xt, ut)
-            x.append(new_x)
-        return torch.stack(x, 0)
+                states.append(dynamics(states[-1], actions[t]))
+        return torch.stack(states, dim=0)
 
-    # ------------------------------------------------------------------ qp_wrapper.py:326-345
+    # ------------------------------------------------------------------ behaviour of qp_wrapper.py:326-345
     def dyn_res(self, x, dx, x0):
-        x = x.reshape(self.n_batch, self.T, self.n_state + self.n_ctrl)
-        x, u = x[:, :, :self.n_state], x[:, :, self.n_state:]
+        """Dynamics residual of a flat trajectory (B, T(n+m)): [f(x_t,u_t) - x_{t+1}]_t, then x_0 - x0."""
+        tau = x.reshape(self.n_batch, self.T, self.n_state + self.n_ctrl)
+        xs, us = tau[..., :self.n_state], tau[..., self.n_state:]
         if isinstance(dx, LinDx):
-            x_next = (dx.F.permute(1, 0, 2, 3) * torch.cat((x, u), dim=2)[:, :-1, None, :]).sum(dim=-1) \
-                + dx.f.permute(1, 0, 2)
+            pred = torch.matmul(dx.F.transpose(0, 1), tau[:, :-1, :, None])[..., 0] + dx.f.transpose(0, 1)
         else:
-            x_next = dx(x.reshape(-1, self.n_state), u.reshape(-1, self.n_ctrl)).reshape(
+            pred = dx(xs.reshape(-1, self.n_state), us.reshape(-1, self.n_ctrl)).reshape(
                 self.n_batch, self.T, self.n_state)[:, :-1]
-        res = (x_next - x[:, 1:, :]).reshape(self.n_batch, -1)
-        res_init = (x[:, 0, :] - x0).reshape(self.n_batch, -1)
-        return torch.cat((res, res_init), dim=1)
+        gaps = (pred - xs[:, 1:]).reshape(self.n_batch, -1)
+        return torch.cat((gaps, xs[:, 0] - x0), dim=1)
 
-    # ------------------------------------------------------------------ qp_wrapper.py:690-692
+    # ------------------------------------------------------------------ behaviour of qp_wrapper.py:690-692
     def compute_cost(self, xu, cost):
-        C = cost.C.transpose(0, 1)
-        c = cost.c.transpose(0, 1)
-        return 0.5 * ((xu.unsqueeze(-1) * C).sum(dim=-2) * xu).sum(dim=-1).sum(dim=-1) + \
-            (xu * c).sum(dim=-1).sum(dim=-1)
+        """Total quadratic cost of batch-major trajectories xu (B,T,n+m) under time-major (C, c)."""
+        Cx = torch.matmul(cost.C.transpose(0, 1), xu[..., None])[..., 0]          # (B,T,n+m)
+        return (xu * (0.5 * Cx + cost.c.transpose(0, 1))).sum(dim=(1, 2))
