@@ -247,7 +247,7 @@ def main():
                         "pdipm_iters_mean": float(iters.mean()), "pdipm_iters_max": float(iters.max()),
                         "status_nonzero": status_bad},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the CPU baseline is an N=1, rank-0 figure
             cb, o = cpu_baseline(host_inputs)
             out["cpu_baseline"] = cb
             err = float(np.abs(hp.zhat.cpu().numpy() - o["zhat"]).max())
