@@ -73,7 +73,7 @@ def family_R(seed, B, nz, nineq, neq):
 class HotPath:
     """Pre-allocated buffers + the two C-ABI calls of one step."""
 
-    def __init__(self, dev, host_inputs):
+    def __init__(self, dev, host_inputs, termination="batch"):
         from diff_qp_mpc_amd import _lib
         self._lib = _lib
         self.lib = _lib.load()
@@ -91,9 +91,14 @@ class HotPath:
         self.dG = torch.empty(B, NINEQ, NZ, **kw); self.dh = torch.empty(B, NINEQ, **kw)
         self.dA = torch.empty(B, NEQ, NZ, **kw); self.db = torch.empty(B, NEQ, **kw)
         self.dims = _lib.dqp_dims(B, NZ, NINEQ, NEQ, NZ * NZ, NZ, NINEQ * NZ, NINEQ, NEQ * NZ, NEQ)
-        self.opts = _lib.dqp_opts(float(os.environ.get("DQP_BENCH_EPS", "1e-12")), 1e-10, 20, 3, 0, 0)
+        # "batch": the reference's batch-coupled stopping rule replayed on the device (parity-safe,
+        # the package default); "per_problem": every QP stops on its own (include/dqp.h)
+        tflag = _lib.DQP_FLAG_BATCH_TERMINATION if termination == "batch" else 0
+        self.opts = _lib.dqp_opts(float(os.environ.get("DQP_BENCH_EPS", "1e-12")), 1e-10, 20, 3, tflag, 0)
         wsb = int(self.lib.dqp_workspace_bytes(ctypes.byref(self.dims)))
         self.ws = torch.empty(max(wsb // 8, 1), **kw)            # caller-owned scratch (include/dqp.h)
+        tb = int(self.lib.dqp_termination_bytes(ctypes.byref(self.dims), ctypes.byref(self.opts)))
+        self.term = torch.empty(max((tb + 7) // 8, 1), **kw)
         self.stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr())
         self.fargs = [P(t) for t in (self.Q, self.p, self.G, self.h, self.A, self.b, self.zhat,
@@ -103,13 +108,14 @@ class HotPath:
                                      self.dA, self.db)]
         self.null = ctypes.c_void_p(0)
         self.wsp = P(self.ws) if wsb > 0 else self.null
+        self.termp = P(self.term) if tb > 0 else self.null
         # backward restarts from the factorisation context forward leaves in the workspace (what the
         # reference keeps on ctx, qp.py:93-95)
         self.bopts = self._lib.dqp_opts(0.0, 0.0, 0, 0, self._lib.DQP_FLAG_BACKWARD_CTX if wsb > 0 else 0, 0)
 
     def forward(self):
         rc = self.lib.dqp_qp_forward(ctypes.byref(self.dims), ctypes.byref(self.opts), *self.fargs,
-                                     self.wsp, self.stream)
+                                     self.wsp, self.termp, self.stream)
         if rc:
             raise RuntimeError("dqp_qp_forward rc=%d" % rc)
 

@@ -31,12 +31,13 @@ DQP_FLAG_DENSE_BACKWARD = 1
 DQP_FLAG_GENERIC_ONLY = 2
 DQP_FLAG_NO_NULLSPACE = 4
 DQP_FLAG_BACKWARD_CTX = 8
+DQP_FLAG_BATCH_TERMINATION = 16
 DQP_STATUS_Q_NOT_PD = 1
 DQP_STATUS_A_RANK_DEF = 2
 DQP_MAX_DIM = 64
 
 # every symbol include/dqp.h declares
-SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes",
+SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termination_bytes",
            "dqp_qp_forward", "dqp_qp_backward", "dqp_mpc_assemble", "dqp_mpc_assemble_backward",
            "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble", "dqp_al_merit")
 
@@ -83,7 +84,9 @@ def load():
     lib.dqp_workspace_bytes.restype = ctypes.c_size_t
     lib.dqp_workspace_bytes.argtypes = [ctypes.POINTER(dqp_dims)]
     lib.dqp_qp_forward.restype = ctypes.c_int
-    lib.dqp_qp_forward.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 14
+    lib.dqp_termination_bytes.restype = ctypes.c_size_t
+    lib.dqp_termination_bytes.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)]
+    lib.dqp_qp_forward.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 15
     lib.dqp_qp_backward.restype = ctypes.c_int
     lib.dqp_qp_backward.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 17
     lib.dqp_mpc_assemble.restype = ctypes.c_int

@@ -26,13 +26,43 @@ struct KParams {
     double eps, stallTol;
     int maxIter, notImprovedLim;
     unsigned flags;
+    // batch-coupled termination (DQP_FLAG_BATCH_TERMINATION, dqp_term.hip)
+    double *hist;          // pass 1: (B, histIters, 2) = (resid, mu) per iteration, or NULL
+    const int32_t *cap;    // pass 2: cap[0] = iteration cap, cap[TERM_HDR + qp] = re-solve this QP
+    int histIters;
 };
+
+constexpr int TERM_HDR = 8;   // int32 header words in front of the redo list
+
+// Record one iteration of a problem's residual history (one lane per problem calls this).
+__device__ __forceinline__ void hist_put(const KParams &P, long long qp, int it, double resid, double mu)
+{
+    double2 *h = reinterpret_cast<double2 *>(P.hist) + qp * P.histIters + it;
+    *h = make_double2(resid, mu);
+}
+// The problem left the loop after `iters` iterations: the rest of its history is NaN (what the
+// reference's iterate is from there on: a non-finite residual never recovers, batch.py:119-131).
+__device__ __forceinline__ void hist_fill(const KParams &P, long long qp, int iters)
+{
+    double2 *h = reinterpret_cast<double2 *>(P.hist) + qp * P.histIters;
+    const double nan = __builtin_nan("");
+    for (int it = iters; it < P.histIters; ++it) h[it] = make_double2(nan, nan);
+}
+
+// batch rule replay + redo list (dqp_term.hip); 0 on success
+size_t term_bytes(int B, int maxIter);
+int term_decide(const KParams &P, void *term, void *stream);
+void term_bind_pass1(KParams &P, void *term);
+void term_bind_pass2(KParams &P, void *term);
+int term_clear(const KParams &P, void *term, void *stream);
 
 
 // DPP-row kernels (dqp_r16.hip): 4 QPs per wavefront for compile-time sizes <= 32.
 // Return DQP_OK / error, or 1 when no instantiation matches (caller falls back to the
 // generic kernels of dqp_pdipm.hip).
+#ifdef DQP_STAMPS
 extern unsigned long long *g_debug_stamps;
+#endif
 int r16_forward(const KParams &P, void *stream);
 int r16_backward(const KParams &P, void *stream);
 // null-space form of the forward kernel (dqp_r16n.hip); same return convention.  It parks

@@ -443,6 +443,12 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
     const Lds S = carve(sm, P);
 
     double rdq, rd1;
+    int maxIter = P.maxIter;
+    const bool batch = (P.flags & DQP_FLAG_BATCH_TERMINATION) != 0;
+    if (P.cap) {        // pass 2 of the batch rule: only the listed QPs, up to the reference's stop
+        if (P.cap[TERM_HDR + qp] == 0) return;
+        maxIter = min(maxIter, P.cap[0]);
+    }
     const int status = qp_setup(P, S, qp, lane, rdq, rd1);
     const bool inN = lane < N, inM = lane < M, inE = lane < E;
 
@@ -472,7 +478,7 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
     bool have_best = false;
     int nNotImproved = 0, iters = 0;
 
-    for (int it = 0; it < P.maxIter; ++it) {
+    for (int it = 0; it < maxIter; ++it) {
         // residuals in hat coordinates                                   batch.py:93-108
         double rxh = xh + ph + matvecT<MAXM>(S.Gh, P.ldz, M, N, z, lane);
         double ryt = 0.0;
@@ -498,8 +504,11 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
         } else {
             nNotImproved += 1;
         }
-        if ((nNotImproved >= P.notImprovedLim && best < P.stallTol) || best < P.eps ||
-            mu > 1e32 || !(fabs(resid) < INFINITY))
+        if (batch) {                           // the stop is decided over the batch (dqp_term.hip)
+            if (P.hist && lane == 0) hist_put(P, qp, it, resid, mu);
+            if (!(fabs(resid) < INFINITY)) break;
+        } else if ((nNotImproved >= P.notImprovedLim && best < P.stallTol) || best < P.eps ||
+                   mu > 1e32 || !(fabs(resid) < INFINITY))
             break;
 
         const double dinv = inM ? s / z : 0.0;                          // 1/d, d = z/s
@@ -527,6 +536,7 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
         yt += alpha * dyt;
     }
 
+    if (P.hist && lane == 0) hist_fill(P, qp, iters);
     // back to the caller's coordinates: x = Lq^-T xh, y = L1^-T yt
     const double x = trsv_LT(S.Lq, P.ldz, N, bxh, rdq, lane);
     if (inN) P.zhat[(long long)qp * N + lane] = x;
@@ -608,7 +618,11 @@ __global__ __launch_bounds__(WAVE) void qp_backward_kernel(KParams P)
 
 int fill_params(const dqp_dims *d, const dqp_opts *o, KParams &P, size_t &lds_bytes)
 {
+#ifdef DQP_STAMPS
     P.stamps = dqp::g_debug_stamps;
+#else
+    P.stamps = nullptr;
+#endif
     if (!d) return DQP_ERR_BAD_ARG;
     if (d->nbatch < 0 || d->nz <= 0 || d->nineq <= 0 || d->neq < 0) return DQP_ERR_BAD_ARG;
     if (d->nz > DQP_MAX_DIM || d->nineq > DQP_MAX_DIM || d->neq > DQP_MAX_DIM) return DQP_ERR_TOO_LARGE;
@@ -628,6 +642,7 @@ int fill_params(const dqp_dims *d, const dqp_opts *o, KParams &P, size_t &lds_by
     P.maxIter = o ? o->max_iter : 20;
     P.notImprovedLim = o ? o->not_improved_lim : 3;
     P.flags = o ? o->flags : 0u;
+    P.hist = nullptr; P.cap = nullptr; P.histIters = P.maxIter;
     size_t n = (size_t)P.N * P.ldz + (size_t)P.M * P.ldz + (size_t)P.E * P.ldz +
                (size_t)P.E * P.lde + (size_t)P.M * (P.ldm > P.lde ? P.ldm : P.lde) +
                (size_t)P.M * P.ldt;
@@ -652,16 +667,21 @@ int launch(K kernel, const KParams &P, size_t lds_bytes, void *stream)
 
 }  // namespace
 
+#ifdef DQP_STAMPS
 namespace dqp { unsigned long long *g_debug_stamps = nullptr; }
+#endif
 
 extern "C" {
 
-// Diagnostic hook (not part of include/dqp.h): device buffer of 16 x uint64 per workgroup that
-// the DPP-row kernels fill with s_memtime stamps at phase boundaries; NULL disables.
+#ifdef DQP_STAMPS
+// Diagnostic hook of the instrumented build only (tools/stamps.py compiles libdqp_hip_stamps.so
+// with -DDQP_STAMPS; the shipped library has neither this symbol nor any state): device buffer
+// of 16 x uint64 per workgroup that the DPP-row kernels fill with s_memtime stamps.
 __attribute__((visibility("default"))) void dqp_debug_set_stamps(void *dev_ptr)
 {
     dqp::g_debug_stamps = (unsigned long long *)dev_ptr;
 }
+#endif
 
 __attribute__((visibility("default"))) int dqp_version(void) { return DQP_VERSION; }
 
@@ -683,11 +703,20 @@ __attribute__((visibility("default"))) size_t dqp_workspace_bytes(const dqp_dims
     return (size_t)d->nbatch * (size_t)dqp::r16n_workspace_doubles(d->nz, d->nineq, d->neq) * sizeof(double);
 }
 
+__attribute__((visibility("default"))) size_t
+dqp_termination_bytes(const dqp_dims *d, const dqp_opts *o)
+{
+    if (!d || d->nbatch <= 0 || !o || !(o->flags & DQP_FLAG_BATCH_TERMINATION)) return 0;
+    return dqp::term_bytes(d->nbatch, o->max_iter);
+}
+
+static int forward_once(const KParams &P, size_t lds, void *workspace, void *stream);
+
 __attribute__((visibility("default"))) int
 dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, const double *p,
                const double *G, const double *h, const double *A, const double *b, double *zhat,
                double *lam, double *nu, double *slack, int32_t *info, double *best_resid,
-               void *workspace, void *stream)
+               void *workspace, void *termination, void *stream)
 {
     KParams P = {};
     size_t lds = 0;
@@ -700,6 +729,26 @@ dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, cons
     P.Q = Q; P.p = p; P.G = G; P.h = h; P.A = A; P.b = b;
     P.zhat = zhat; P.lam = lam; P.nu = nu; P.slack = slack;
     P.info = info; P.best_resid = best_resid;
+    if (!(P.flags & DQP_FLAG_BATCH_TERMINATION)) return forward_once(P, lds, workspace, stream);
+    // The reference's batch-coupled stop (batch.py:119-144), replayed on the device:
+    //   1. every problem iterates to max_iter, recording (resid, mu) per iteration;
+    //   2. the batch rule is evaluated on that history -> the iteration the reference stops at,
+    //      and the list of problems whose best iterate came after it;
+    //   3. those problems (none in a large batch) are solved again up to that iteration.
+    // Five enqueues on `stream`, no host synchronisation, hipGraph-capturable.
+    if (!termination || P.maxIter < 1 || P.maxIter > 64) return DQP_ERR_BAD_ARG;
+    P.eps = opts ? opts->eps : 1e-12;            // the batch rule uses the reference's eps itself
+    if ((rc = term_clear(P, termination, stream)) != DQP_OK) return rc;
+    term_bind_pass1(P, termination);
+    if ((rc = forward_once(P, lds, workspace, stream)) != DQP_OK) return rc;
+    if ((rc = term_decide(P, termination, stream)) != DQP_OK) return rc;
+    term_bind_pass2(P, termination);
+    return forward_once(P, lds, workspace, stream);
+}
+
+static int forward_once(const KParams &P, size_t lds, void *workspace, void *stream)
+{
+    int rc;
     if (!(P.flags & DQP_FLAG_GENERIC_ONLY)) {
         // DPP-row kernels for the instantiated sizes: the null-space form when the caller gave
         // it its workspace (and did not opt out), else the form that keeps the equality rows.

@@ -270,8 +270,15 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
     long long qp = (long long)blockIdx.x * 4 + qrow;
-    const bool live = qp < P.B;
+    bool live = qp < P.B;
     if (!live) qp = P.B - 1;                     // duplicate the last QP; its stores are masked
+    int maxIter = P.maxIter;
+    const bool batch = (P.flags & DQP_FLAG_BATCH_TERMINATION) != 0;
+    if (P.cap) {        // pass 2 of the batch rule: only the listed QPs, up to the reference's stop
+        maxIter = min(maxIter, P.cap[0]);
+        live = live && P.cap[TERM_HDR + qp] != 0;
+        if (__builtin_amdgcn_ballot_w64(live) == 0) return;
+    }
     double *lds = sm + qrow * C::ldsQPpad;
 
     State<C> st;
@@ -346,7 +353,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     bool have_best = false, done = false;
     int nNot = 0, iters = 0;
 
-    for (int it = 0; it < P.maxIter; ++it) {
+    for (int it = 0; it < maxIter; ++it) {
         // residuals in hat coordinates                                    batch.py:93-108
         double rxh[SN], ryt[SE], rz[SM], tmpN[SN];
         vec_get<SN>(lds + C::oPh, tmpN, N, r);
@@ -398,8 +405,11 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             } else {
                 nNot += 1;
             }
-            if ((nNot >= P.notImprovedLim && best < P.stallTol) || best < P.eps || mu > 1e32 ||
-                !(fabs(resid) < INFINITY))
+            if (batch) {                       // the stop is decided over the batch (dqp_term.hip)
+                if (P.hist && r == 0 && live) hist_put(P, qp, it, resid, mu);
+                done = !(fabs(resid) < INFINITY);
+            } else if ((nNot >= P.notImprovedLim && best < P.stallTol) || best < P.eps || mu > 1e32 ||
+                       !(fabs(resid) < INFINITY))
                 done = true;
         }
         // the wave leaves when all four of its QPs are done
@@ -479,6 +489,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
         }
     }
 
+    if (P.hist && r == 0 && live) hist_fill(P, qp, iters);
     // back to the caller's coordinates: x = Lq^-T xh, y = L1^-T yt
     STAMP(P, 7);
     double bxh[SN], bs[SM], bz[SM], byt[SE];

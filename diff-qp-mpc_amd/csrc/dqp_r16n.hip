@@ -246,6 +246,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(P, 1);
 
     // B: rows of G, A times Lq^-T (Lq[j][k] read row-uniformly from LDS)
     load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
@@ -277,6 +278,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(P, 2);
 
 #pragma unroll
     for (int s = 0; s < SE; ++s) { st.tau[s] = 0.0; st.rdu1[s] = 0.0; st.xy[s] = 0.0; st.py[s] = 0.0; st.w1[s] = 0.0; }
@@ -357,6 +359,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(P, 3);
 
     {   // E: ph = Lq^-1 p ; [cp ; py] = Qf^T ph
         double ph[SN];
@@ -394,6 +397,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         vec_put<SM>(lds + C::oHp, hp, M, r, dummy);
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(P, 4);
 
     {   // G: LqZ = (Lq Qf)[:, :R] ;  qv = (Lq Qf)[:, R:] w1
         double Ld[SN][N];
@@ -451,6 +455,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         vec_put<SN>(lds + C::oQv, qv, N, r, dummy);
     }
     __builtin_amdgcn_sched_barrier(0);
+    STAMP(P, 5);
 
     // H: the reflector tails are done for now: park them in the caller's workspace (read back
     // for the epilogue), then Rm = Gz Gz^T goes, packed, into the same LDS region.
@@ -546,13 +551,22 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
     long long qp = (long long)blockIdx.x * 4 + qrow;
-    const bool live = qp < P.B;
+    bool live = qp < P.B;
     if (!live) qp = P.B - 1;                     // duplicate the last QP; its stores are masked
+    int maxIter = P.maxIter;
+    const bool batch = (P.flags & DQP_FLAG_BATCH_TERMINATION) != 0;
+    if (P.cap) {        // pass 2 of the batch rule: only the listed QPs, up to the reference's stop
+        maxIter = min(maxIter, P.cap[0]);
+        live = live && P.cap[TERM_HDR + qp] != 0;
+        if (__builtin_amdgcn_ballot_w64(live) == 0) return;
+    }
     double *lds = sm + qrow * C::ldsQPpad;
     double *dummy = lds + C::oDummy + r;
 
     State<C> st;
+    STAMP(P, 0);
     setup<C>(P, qp, r, lds, st);
+    STAMP(P, 15);
 
     bool inM[SM], inR[SR];
 #pragma unroll
@@ -599,11 +613,12 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     // gz = Gz^T z is carried incrementally (updated with the step's own transposed product)
     double gz[SR];
     mul_GzT<C>(st, z, gz, r);
+    STAMP(P, 6);
     double best = INFINITY, bestc = 1.0;
     bool have_best = false, done = false;
     int nNot = 0, iters = 0;
 
-    for (int it = 0; it < P.maxIter; ++it) {
+    for (int it = 0; it < maxIter; ++it) {
         // residuals                                                        batch.py:93-108
         double rw[SR], rz[SM];
         {
@@ -634,12 +649,16 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             } else {
                 nNot += 1;
             }
-            if ((nNot >= P.notImprovedLim && best < P.stallTol) || best < P.eps || mu > 1e32 ||
-                !(fabs(resid) < INFINITY))
+            if (batch) {                       // the stop is decided over the batch (dqp_term.hip)
+                if (P.hist && r == 0 && live) hist_put(P, qp, it, resid, mu);
+                done = !(fabs(resid) < INFINITY);
+            } else if ((nNot >= P.notImprovedLim && best < P.stallTol) || best < P.eps || mu > 1e32 ||
+                       !(fabs(resid) < INFINITY))
                 done = true;
         }
         // the wave leaves when all four of its QPs are done
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+        if (it == 1) STAMP(P, 9);
 
         // phase 1 (Gz live, T dead): affine right-hand side  g = rz - rs/d - Gz rw,  rs/d = s
         double dza[SM], dsa[SM];
@@ -655,7 +674,9 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
 #pragma unroll
         for (int s = 0; s < SM; ++s) dinv[s] = inM[s] ? s_[s] * frcp(z[s]) : 0.0;   // 1/d, d = z/s
         factor_T<C>(lds, T, st.rdiag, dinv, rdu, r);
+        if (it == 1) STAMP(P, 10);
         lu_solve<SM, M>(T, rdu, dza, r);
+        if (it == 1) STAMP(P, 11);
         double rzv[SM], rsv[SM];           // formed only now: not live across the factorisation
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
@@ -684,6 +705,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             dzc[s] = -rsc[s] * dinv[s];
         }
         lu_solve<SM, M>(T, rdu, dzc, r);
+        if (it == 1) STAMP(P, 12);
         tm = 0.0;
 #pragma unroll
         for (int s = 0; s < SM; ++s) {
@@ -706,8 +728,12 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             for (int s = 0; s < SM; ++s) { s_[s] = fma(alpha, ds[s], s_[s]); z[s] = fma(alpha, dz[s], z[s]); }
             cc *= (1.0 - alpha);
         }
+        if (it == 1) STAMP(P, 13);
+        if (it == 0) STAMP(P, 8);
     }
+    STAMP(P, 7);
 
+    if (P.hist && r == 0 && live) hist_fill(P, qp, iters);
     // the reflector tails come back from the workspace into the (now idle) Gz Gz^T region
     __syncthreads();
     if (E > 0) {
@@ -755,6 +781,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             if (P.best_resid) P.best_resid[qp] = best;
         }
     }
+    STAMP(P, 14);
 }
 
 // Backward pass in the same null-space coordinates (reference: qp.py:128-183 = factor_kkt +

@@ -5,7 +5,9 @@ Differences from the reference, all documented in DESIGN.md:
   * `dyn_res` / `cost_grad` are accepted positionally (qp.py:24) but the fused kernel
     evaluates the linear forms dyn_res(x) = A x - b and cost_grad(x) = Q x + p on chip;
     pass `check_callables=True` to verify a supplied closure against them at one point.
-  * termination is per problem, not batch-coupled (include/dqp.h).
+  * termination: the reference's batch-coupled rule (batch.py:119-144) is reproduced on the
+    device by default (TERMINATION = "batch"); "per_problem" lets every problem stop on its own
+    (include/dqp.h) -- faster in very large batches, float-tolerance parity.
   * `check_Q_spd` uses the kernel's Cholesky status instead of B host-side eig calls.
   * solver=QPSolvers.CVXPY is not available (cvxpy is an offline oracle in the reference).
 """
@@ -30,6 +32,9 @@ Your problem may be infeasible or difficult.
 
 # per-problem early exit only once the best residual is below this (include/dqp.h)
 STALL_TOL = 1e-10
+# "batch": DQP_FLAG_BATCH_TERMINATION, the reference's stopping rule replayed over the batch (the
+# default of every operator in this package); "per_problem": each problem stops on its own
+TERMINATION = "batch"
 # extra dqp_opts.flags OR-ed into every call (tests use DQP_FLAG_GENERIC_ONLY / _NO_NULLSPACE to
 # pin a kernel family; 0 = automatic dispatch)
 FORCE_FLAGS = 0
@@ -71,8 +76,11 @@ def _require_gpu(*ts):
                 "There is no CPU fallback." % t.device)
 
 
-def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim):
+def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim, termination=None):
     _require_gpu(Q_, p_, G_, h_, A_, b_)
+    termination = termination or TERMINATION
+    if termination not in ("batch", "per_problem"):
+        raise ValueError("termination must be 'batch' or 'per_problem'")
     lib = _lib.load()
     nBatch = extract_nBatch(Q_, p_, G_, h_, A_, b_)
     Q, sQ = _prep(Q_, 3)
@@ -86,7 +94,8 @@ def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim):
     assert neq > 0 or nineq > 0                                   # qp.py:90
     dev = Q.device
     dims = _lib.dqp_dims(nBatch, nz, nineq, neq, sQ, sp, sG, sh, sA, sb)
-    opts = _lib.dqp_opts(eps, STALL_TOL, maxIter, notImprovedLim, FORCE_FLAGS, 0)
+    flags = FORCE_FLAGS | (_lib.DQP_FLAG_BATCH_TERMINATION if termination == "batch" else 0)
+    opts = _lib.dqp_opts(eps, STALL_TOL, maxIter, notImprovedLim, flags, 0)
     kw = dict(dtype=torch.float64, device=dev)
     zhat = torch.empty(nBatch, nz, **kw)
     lam = torch.empty(nBatch, nineq, **kw)
@@ -97,10 +106,13 @@ def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim):
     # scratch for the null-space forward kernels (include/dqp.h: dqp_workspace_bytes)
     wsb = int(lib.dqp_workspace_bytes(ctypes.byref(dims)))
     ws = torch.empty(wsb // 8, **kw) if wsb > 0 else None
+    tb = int(lib.dqp_termination_bytes(ctypes.byref(dims), ctypes.byref(opts)))
+    term = torch.empty((tb + 7) // 8, **kw) if tb > 0 else None
     with torch.cuda.device(dev):
         rc = lib.dqp_qp_forward(ctypes.byref(dims), ctypes.byref(opts), _ptr(Q), _ptr(p), _ptr(G),
                                 _ptr(h), _ptr(A), _ptr(b), _ptr(zhat), _ptr(lam), _ptr(nu),
-                                _ptr(slack), _ptr(info), _ptr(resid), _ptr(ws), _stream(dev))
+                                _ptr(slack), _ptr(info), _ptr(resid), _ptr(ws), _ptr(term),
+                                _stream(dev))
     _lib.check(rc, "dqp_qp_forward")
     # the workspace now holds the factorisation context backward can restart from (include/dqp.h)
     ctx_ws = ws if (ws is not None and not (FORCE_FLAGS & (_lib.DQP_FLAG_NO_NULLSPACE | _lib.DQP_FLAG_GENERIC_ONLY))) else None

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DQP_VERSION 100 /* 0.1.0 */
+#define DQP_VERSION 200 /* 0.2.0: dqp_qp_forward takes a termination buffer */
 #define DQP_MAX_DIM 64
 
 enum {
@@ -56,6 +56,16 @@ enum {
                                       for the SAME Q, G, A (it holds the factorisations, like the
                                       reference's ctx.Q_LU / S_LU / R, qp.py:93-95): skip the
                                       refactorisation.  Ignored where no such kernel exists.   */
+#define DQP_FLAG_BATCH_TERMINATION 16u /* forward: the reference's batch-coupled stopping rule
+                                      (batch.py:119-144), exactly: every problem is iterated to
+                                      max_iter while its (resid, mu) history is recorded in
+                                      `termination`, a reduction over the batch replays the
+                                      reference's rule (no sample improved for not_improved_lim
+                                      iterations | best_resids.max() < eps | mu.min() > 1e32) to
+                                      find the iteration the reference stops at, and the problems
+                                      whose best iterate came later are re-solved up to there.  Needs
+                                      the `termination` buffer (dqp_termination_bytes).  Without the
+                                      flag a problem stops on its own (see dqp_qp_forward).        */
 #define DQP_FLAG_NO_NULLSPACE 4u   /* forward: keep the equality rows in the iteration even when a
                                       workspace is given (the kernel used without one)       */
 
@@ -90,6 +100,10 @@ const char *dqp_error_string(int code);
  * the refactorisation (2x faster backward).  Without that flag backward needs no workspace. */
 size_t dqp_workspace_bytes(const dqp_dims *dims);
 
+/* Bytes of the device buffer DQP_FLAG_BATCH_TERMINATION needs (per-iteration residual history,
+ * the batch reduction's accumulators and the redo list); 0 without the flag.  max_iter <= 64. */
+size_t dqp_termination_bytes(const dqp_dims *dims, const dqp_opts *opts);
+
 /*
  * Replaces: qpth.qp.QPFunction(...).forward  (qpth/qp.py:24-126) =
  *           pdipm_b.pre_factor_kkt + pdipm_b.forward (qpth/solvers/pdipm/batch.py:377-428,
@@ -99,7 +113,9 @@ size_t dqp_workspace_bytes(const dqp_dims *dims);
  * Outputs: zhat (B,nz); lam (B,nineq), nu (B,neq), slack (B,nineq) -- what the reference
  *          stashes on ctx for backward (qp.py:95,125); info (B,2) int32 = {status, PDIPM
  *          iterations run}; best_resid (B) or NULL.
- * Termination is per problem.  The reference's rule is batch-coupled (batch.py:127-144: stop
+ * Termination: with DQP_FLAG_BATCH_TERMINATION the reference's batch-coupled rule is reproduced
+ * exactly (what the Python mirrors use by default).  Without it, termination is per problem
+ * (faster in batches larger than the GPU holds at once, float-tolerance parity): the reference's rule is batch-coupled (batch.py:127-144: stop
  * when NO sample improved for not_improved_lim consecutive iterations, so in a large batch
  * every sample effectively runs max_iter iterations).  Here a problem stops when (a) it has
  * not improved for not_improved_lim consecutive iterations AND its best residual is already
@@ -116,7 +132,7 @@ int dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts,
                    const double *A, const double *b,
                    double *zhat, double *lam, double *nu, double *slack,
                    int32_t *info, double *best_resid,
-                   void *workspace, void *stream);
+                   void *workspace, void *termination, void *stream);
 
 /*
  * Replaces: QPFunctionFn.backward (qpth/qp.py:128-183) = factor_kkt + solve_kkt

@@ -363,13 +363,13 @@ API int dqp_oracle_max_threads(void)
  * of PDIPM iterations the batch executed; best_resid (B) may be NULL.
  * Returns 0; 1 if LU(Q) failed (reference raises RuntimeError, batch.py:381-388).
  */
-API int dqp_oracle_qp_forward(int B, int nz, int nineq, int neq,
-                              const double *Q, const double *p, const double *G,
-                              const double *h, const double *A, const double *b,
-                              double eps, int notImprovedLim, int maxIter,
-                              double *zhat, double *lam, double *nu, double *slack,
-                              int *iters_out, double *best_resid, double *resid_hist,
-                              int nthreads)
+static int qp_forward_impl(int B, int nz, int nineq, int neq,
+                           const double *Q, const double *p, const double *G,
+                           const double *h, const double *A, const double *b,
+                           double eps, int notImprovedLim, int maxIter,
+                           double *zhat, double *lam, double *nu, double *slack,
+                           int *iters_out, double *best_resid, double *resid_hist,
+                           int nthreads, int dv0_guard)
 {
     /* resid_hist (B, maxIter) or NULL: diagnostic trace of `resids` (batch.py:108) per
      * iteration, NaN where the batch had already stopped. */
@@ -438,8 +438,8 @@ API int dqp_oracle_qp_forward(int B, int nz, int nineq, int neq,
             for (int i = 0; i < B; ++i) {
                 qpws *w = &W[i];
                 solve_kkt(w, w->rx, w->rs, w->rz, w->ry, w->dxa, w->dsa, w->dza, w->dya);
-                w->amax_z = step_ratio(nineq, w->z, w->dza, w->dzc, 0);  /* dzc/dsc as scratch */
-                w->amax_s = step_ratio(nineq, w->s, w->dsa, w->dsc, 0);
+                w->amax_z = step_ratio(nineq, w->z, w->dza, w->dzc, dv0_guard);  /* dzc/dsc as scratch */
+                w->amax_s = step_ratio(nineq, w->s, w->dsa, w->dsc, dv0_guard);
             }
             for (int i = 0; i < B; ++i) { amz = tmax(amz, W[i].amax_z); ams = tmax(ams, W[i].amax_s); }
 #pragma omp parallel for num_threads(nthreads) schedule(static)
@@ -464,8 +464,8 @@ API int dqp_oracle_qp_forward(int B, int nz, int nineq, int neq,
                 for (int k = 0; k < nz; ++k) w->dxa[k] += w->dxc[k];
                 for (int k = 0; k < nineq; ++k) { w->dsa[k] += w->dsc[k]; w->dza[k] += w->dzc[k]; }
                 for (int k = 0; k < neq; ++k) w->dya[k] += w->dyc[k];
-                w->amax_z = step_ratio(nineq, w->z, w->dza, w->dzc, 0);
-                w->amax_s = step_ratio(nineq, w->s, w->dsa, w->dsc, 0);
+                w->amax_z = step_ratio(nineq, w->z, w->dza, w->dzc, dv0_guard);
+                w->amax_s = step_ratio(nineq, w->s, w->dsa, w->dsc, dv0_guard);
             }
             amz = -INFINITY; ams = -INFINITY;
             for (int i = 0; i < B; ++i) { amz = tmax(amz, W[i].amax_z); ams = tmax(ams, W[i].amax_s); }
@@ -492,6 +492,44 @@ API int dqp_oracle_qp_forward(int B, int nz, int nineq, int neq,
     if (iters_out) iters_out[0] = iters;
     free(buf); free(ibuf); free(W);
     return fail ? 1 : 0;
+}
+
+API int dqp_oracle_qp_forward(int B, int nz, int nineq, int neq,
+                              const double *Q, const double *p, const double *G,
+                              const double *h, const double *A, const double *b,
+                              double eps, int notImprovedLim, int maxIter,
+                              double *zhat, double *lam, double *nu, double *slack,
+                              int *iters_out, double *best_resid, double *resid_hist,
+                              int nthreads)
+{
+    return qp_forward_impl(B, nz, nineq, neq, Q, p, G, h, A, b, eps, notImprovedLim, maxIter, zhat,
+                           lam, nu, slack, iters_out, best_resid, resid_hist, nthreads, 0);
+}
+
+/*
+ * The same forward with get_step taken from the reference's OTHER PDIPM module
+ * (batch_LU.py:204-210: `a[dv == 0] = 1.0` before the min) instead of batch.py:211-214.
+ * Why it exists: batch.py's get_step computes -v/dv with no guard, so a step component that
+ * rounds to exactly 0.0 (typical for the slack of an inactive box bound late in the solve:
+ * dz_aff == -z bit for bit) gives -inf, alpha = -inf, 0 * inf = NaN, and that sample's iterate
+ * is NaN for the rest of the batch's iterations -- its returned "best" is frozen one or two
+ * iterations before convergence (mu ~ 1e-14 instead of ~ 1e-17).  Which samples hit an exact
+ * zero is a floating-point accident of the reference's arithmetic order, not a property of the
+ * QP; the fused kernels (different coordinates, reciprocal-based step rule) sail past it.
+ * Parity for those samples is therefore checked against this variant, which is pinned by
+ * tests/golden/Mz_guard_b8.npz (the reference itself run with pdipm_b.get_step replaced by
+ * batch_LU.get_step, see tests/golden/make_golden_guard.py).
+ */
+API int dqp_oracle_qp_forward_guarded(int B, int nz, int nineq, int neq,
+                                      const double *Q, const double *p, const double *G,
+                                      const double *h, const double *A, const double *b,
+                                      double eps, int notImprovedLim, int maxIter,
+                                      double *zhat, double *lam, double *nu, double *slack,
+                                      int *iters_out, double *best_resid, double *resid_hist,
+                                      int nthreads)
+{
+    return qp_forward_impl(B, nz, nineq, neq, Q, p, G, h, A, b, eps, notImprovedLim, maxIter, zhat,
+                           lam, nu, slack, iters_out, best_resid, resid_hist, nthreads, 1);
 }
 
 /* dQ = 1/2 (dx z^T + z dx^T), dp = dx, dG = dlam z^T + lam dx^T, dh = -dlam,

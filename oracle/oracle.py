@@ -50,8 +50,12 @@ def max_threads():
     return int(lib().dqp_oracle_max_threads())
 
 
-def qp_forward(Q, p, G, h, A, b, eps=1e-12, notImprovedLim=3, maxIter=20, nthreads=0):
-    """batch.py:46-208 restated.  Returns dict(zhat, lam, nu, slack, iters, best_resid)."""
+def qp_forward(Q, p, G, h, A, b, eps=1e-12, notImprovedLim=3, maxIter=20, nthreads=0, guard=False):
+    """batch.py:46-208 restated.  Returns dict(zhat, lam, nu, slack, iters, best_resid, resid_hist).
+
+    guard=True: get_step as in the reference's batch_LU.py:204-210 (a[dv == 0] = 1) instead of
+    batch.py:211-214, whose unguarded -v/dv turns a sample's iterate into NaN for good as soon as
+    one step component is exactly 0.0 (see dqp_oracle.c: dqp_oracle_qp_forward_guarded)."""
     Q, p, G, h = _c(Q), _c(p), _c(G), _c(h)
     B, nz = p.shape
     nineq = h.shape[1]
@@ -61,7 +65,8 @@ def qp_forward(Q, p, G, h, A, b, eps=1e-12, notImprovedLim=3, maxIter=20, nthrea
     zhat = np.empty((B, nz)); lam = np.empty((B, nineq)); slack = np.empty((B, nineq))
     nu = np.empty((B, neq)); res = np.empty(B); hist = np.empty((B, maxIter))
     it = ctypes.c_int(0)
-    rc = lib().dqp_oracle_qp_forward(
+    fn = lib().dqp_oracle_qp_forward_guarded if guard else lib().dqp_oracle_qp_forward
+    rc = fn(
         B, nz, nineq, neq, _p(Q), _p(p), _p(G), _p(h), _p(A), _p(b),
         ctypes.c_double(eps), notImprovedLim, maxIter,
         _p(zhat), _p(lam), _p(nu), _p(slack), ctypes.byref(it), _p(res), _p(hist), nthreads)

@@ -41,12 +41,12 @@ def test_argument_validation_without_gpu(lib):
     from diff_qp_mpc_amd import _lib
     z = ctypes.c_void_p(0)
     d = _lib.dqp_dims(4, 65, 3, 0, 0, 0, 0, 0, 0, 0)
-    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 14)) == -2
+    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 15)) == -2
     d = _lib.dqp_dims(4, 5, 3, 2, 0, 0, 0, 0, 0, 0)
-    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 14)) == -1   # null pointers
+    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 15)) == -1   # null pointers
     assert lib.dqp_qp_backward(ctypes.byref(d), None, *([z] * 17)) == -1
     d = _lib.dqp_dims(0, 5, 3, 2, 0, 0, 0, 0, 0, 0)
-    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 14)) == 0    # empty batch: no launch
+    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 15)) == 0    # empty batch: no launch
 
 
 def test_workspace_bytes_is_a_host_function(lib):
@@ -70,11 +70,11 @@ def test_mpc_argument_validation_without_gpu(lib):
     from diff_qp_mpc_amd import _lib
     z = ctypes.c_void_p(0)
     d = _lib.dqp_mpc_dims(4, 3, 3, 1, 1, 0)                       # T < 2
-    assert lib.dqp_mpc_assemble(ctypes.byref(d), *([z] * 14)) == -1
+    assert lib.dqp_mpc_assemble(ctypes.byref(d), *([z] * 15)) == -1
     d = _lib.dqp_mpc_dims(4, 3, 3, 5, 1, 0)                       # null pointers
-    assert lib.dqp_mpc_assemble(ctypes.byref(d), *([z] * 14)) == -1
+    assert lib.dqp_mpc_assemble(ctypes.byref(d), *([z] * 15)) == -1
     d = _lib.dqp_mpc_dims(0, 3, 3, 5, 1, 0)                       # empty batch
-    assert lib.dqp_mpc_assemble(ctypes.byref(d), *([z] * 14)) == 0
+    assert lib.dqp_mpc_assemble(ctypes.byref(d), *([z] * 15)) == 0
     assert lib.dqp_mpc_assemble_backward(ctypes.byref(d), *([z] * 10)) == 0
 
 

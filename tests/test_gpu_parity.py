@@ -17,6 +17,7 @@ import pytest
 import torch
 
 from oracle import oracle
+from families import family, family_mpc, broke_down
 
 pytestmark = pytest.mark.gpu
 
@@ -61,17 +62,21 @@ def dev(a, grad=True):
 
 
 def family_R(seed, B, nz, nineq, neq):
-    g = torch.Generator().manual_seed(seed)
-    L = torch.randn(B, nz, nz, generator=g, dtype=torch.float64)
-    Q = L @ L.transpose(1, 2) + 1e-3 * torch.eye(nz, dtype=torch.float64)
-    G = torch.randn(B, nineq, nz, generator=g, dtype=torch.float64)
-    z0 = torch.randn(B, nz, generator=g, dtype=torch.float64)
-    s0 = torch.rand(B, nineq, generator=g, dtype=torch.float64)
-    A = torch.randn(B, neq, nz, generator=g, dtype=torch.float64)
-    p = torch.randn(B, nz, generator=g, dtype=torch.float64)
-    h = (G @ z0.unsqueeze(-1)).squeeze(-1) + s0
-    b = (A @ z0.unsqueeze(-1)).squeeze(-1)
-    return [t.numpy() for t in (Q, p, G, h, A, b)]
+    return family(seed, B, nz, nineq, neq, "R")
+
+
+def reference_outputs(ins):
+    """Oracle forward for a stress batch: the strict restatement of batch.py, except on samples
+    where the reference's unguarded get_step divided by an exactly-zero step component and froze
+    the iterate (families.broke_down) -- those are taken from the guarded variant (the reference's
+    own batch_LU.get_step), both pinned by tests/golden (test_oracle_golden.py)."""
+    o = oracle.qp_forward(*ins)
+    bd = broke_down(o["resid_hist"], o["iters"])
+    if bd.any():
+        o2 = oracle.qp_forward(*ins, guard=True)
+        for k in ("zhat", "lam", "nu", "slack", "best_resid"):
+            o[k][bd] = o2[k][bd]
+    return o, bd
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -143,6 +148,57 @@ def test_vs_oracle_seeded(dqp, shape):
         if neq == 0 and k in "Ab":
             continue
         np.testing.assert_allclose(t.grad.cpu().numpy(), og["d" + k], err_msg="d" + k, **GT)
+
+
+@pytest.mark.parametrize("kind,seed", [("M", 0), ("M", 1), ("D", 1), ("D", 3)])
+def test_stress_families_metric_shape(dqp, kind, seed):
+    """Reduced tools/stress_parity.py: B=2048 at the metric shape on the MPC-structured family M
+    (box-constrained, many active and weakly active bounds) and the diagonal-cost family D, every
+    output and every gradient per problem against the oracle.  These are the four batches that
+    held the round-1 outliers (M seed 0 #174/#1889, M seed 1 #1206, D seed 1 #1782, D seed 3
+    #1767): there the reference's batch.py get_step divides by an exactly-zero step component,
+    its iterate turns NaN and its best iterate is frozen 1-2 iterations early, which moves
+    d = lam/slack of weakly active constraints (parity section)."""
+    B, nz, nineq, neq = 2048, 30, 30, 15
+    ins_np = family_mpc(seed, B) if kind == "M" else family(1000 * seed + nz, B, nz, nineq, neq, kind)
+    o, bd = reference_outputs(ins_np)
+    if kind == "M":
+        assert bd.sum() > 0
+    cm = o["best_resid"] < 1e-8
+    assert cm.mean() > 0.99
+    from diff_qp_mpc_amd import qp as qpmod
+    dv = [dev(a, grad=False) for a in ins_np]
+    zhat, lam, nu, slack, info, resid, saved = qpmod._forward_impl(*dv, 1e-12, 20, 3)
+    assert int(info[:, 0].abs().max()) == 0
+    np.testing.assert_allclose(zhat.cpu().numpy()[cm], o["zhat"][cm], **ZT)
+    np.testing.assert_allclose(lam.cpu().numpy()[cm], o["lam"][cm], **DT)
+    np.testing.assert_allclose(nu.cpu().numpy()[cm], o["nu"][cm], **DT)
+    np.testing.assert_allclose(slack.cpu().numpy()[cm], o["slack"][cm], **DT)
+    ct = np.random.default_rng(seed).standard_normal((B, nz))
+    gr = qpmod._backward_impl(saved, zhat, lam, nu, slack, dev(ct, grad=False), (True,) * 6,
+                              qpmod.FORCE_FLAGS)
+    og = oracle.qp_backward(ins_np[0], ins_np[2], ins_np[4], o["zhat"], o["lam"], o["nu"], o["slack"], ct)
+    gm = cm & (np.maximum(o["lam"], o["slack"]).min(1) > 1e-5)       # strict complementarity
+    assert gm.mean() > 0.9
+    for k, t in zip("QpGhAb", gr):
+        np.testing.assert_allclose(t.cpu().numpy()[gm], og["d" + k][gm], err_msg="d" + k, **GT)
+
+
+def test_vs_guarded_reference_golden(dqp):
+    """Mz_guard_b8.npz: on samples 1 and 2 the reference as shipped freezes its iterate early
+    (unguarded get_step, dQ off by up to 0.096 from its own guarded run); the kernels must agree
+    with the guarded run everywhere, and with the strict run on the samples it did not affect."""
+    g = load("Mz_guard_b8")
+    ins = [dev(g["in_" + k]) for k in "QpGhAb"]
+    zhat = dqp.QPFunction(check_Q_spd=True, verbose=-1)(*ins)
+    zhat.backward(dev(g["ct"], grad=False))
+    np.testing.assert_allclose(zhat.detach().cpu().numpy(), g["guard_zhat"], **ZT)
+    unaffected = np.abs(g["strict_dQ"] - g["guard_dQ"]).reshape(8, -1).max(1) < 1e-9
+    assert 0 < unaffected.sum() < 8
+    for k, t in zip("QpGhAb", ins):
+        got = t.grad.cpu().numpy()
+        np.testing.assert_allclose(got, g["guard_d" + k], err_msg="d" + k, **GT)
+        np.testing.assert_allclose(got[unaffected], g["strict_d" + k][unaffected], err_msg="strict d" + k, **GT)
 
 
 def test_full_size_properties_and_oracle(dqp):
@@ -261,7 +317,7 @@ def test_workspace_is_optional(dqp):
         ws = torch.empty(B * per_qp, **kw)
         rc = lib.dqp_qp_forward(ctypes.byref(dims), ctypes.byref(opts), P(Q), P(p), P(G), P(h), P(A),
                                 P(b), P(zhat), P(lam), P(nu), P(slack), P(info), None,
-                                P(ws) if use_ws else None, None)
+                                P(ws) if use_ws else None, None, None)
         assert rc == 0
         torch.cuda.synchronize()
         outs.append([t.cpu().numpy() for t in (zhat, lam, nu, slack)])
@@ -291,8 +347,8 @@ def test_empty_batch_and_bad_dims(dqp):
     lib = _lib.load()
     d = _lib.dqp_dims(4, 65, 3, 0, 0, 0, 0, 0, 0, 0)
     z = ctypes.c_void_p(0)
-    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 14)) == -2      # too large
+    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 15)) == -2      # too large
     d = _lib.dqp_dims(4, 5, 0, 0, 0, 0, 0, 0, 0, 0)
-    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 14)) == -1      # nineq == 0
+    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 15)) == -1      # nineq == 0
     d = _lib.dqp_dims(0, 5, 3, 0, 0, 0, 0, 0, 0, 0)
-    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 14)) == 0       # empty batch
+    assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 15)) == 0       # empty batch

@@ -112,3 +112,38 @@ def test_al_newton_step_oracle_matches_reference(name):
     assert not info.any()
     np.testing.assert_allclose(L, g["ns_L"], rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(upd, g["ns_update"], rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("tag,guard", [("strict", False), ("guard", True)])
+def test_step_rule_variants_match_reference(tag, guard):
+    """Mz_guard_b8.npz (make_golden_guard.py): the reference as is, and the reference with
+    pdipm_b.get_step replaced by its own batch_LU.get_step (a[dv == 0] = 1).  Samples 1 and 2
+    are ones where the unguarded rule divides by an exactly-zero step and freezes the iterate:
+    the two reference runs differ by 0.096 in dQ there, and each oracle variant must reproduce
+    its own run."""
+    g = load("Mz_guard_b8")
+    ins = [g["in_" + k] for k in "QpGhAb"]
+    o = oracle.qp_forward(*ins, guard=guard)
+    np.testing.assert_allclose(o["zhat"], g[tag + "_zhat"], rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(o["lam"], g[tag + "_lam"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(o["slack"], g[tag + "_slack"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(o["nu"], g[tag + "_nu"], rtol=1e-6, atol=1e-9)
+    gr = oracle.qp_backward(ins[0], ins[2], ins[4], o["zhat"], o["lam"], o["nu"], o["slack"], g["ct"])
+    for k in "QpGhAb":
+        np.testing.assert_allclose(gr["d" + k], g[tag + "_d" + k], rtol=1e-5, atol=1e-7, err_msg="d" + k)
+    assert np.abs(g["strict_dQ"] - g["guard_dQ"]).max() > 1e-2      # the fixture does exercise it
+
+
+def test_broke_down_detector():
+    """Late in the solve nearly every family-M sample hits the unguarded division (most of them
+    after they converged, which is harmless); with the guard none does, and the guard changes the
+    returned iterate only on samples that broke down."""
+    from families import broke_down, family_mpc
+    ins = family_mpc(0, 256)
+    o = oracle.qp_forward(*ins)
+    bd = broke_down(o["resid_hist"], o["iters"])
+    assert bd.sum() > 0
+    o2 = oracle.qp_forward(*ins, guard=True)
+    assert not broke_down(o2["resid_hist"], o2["iters"]).any()
+    changed = np.abs(o["slack"] - o2["slack"]).max(1) > 1e-9
+    assert not (changed & ~bd).any()
