@@ -23,7 +23,9 @@ class dqp_opts(ctypes.Structure):
     _fields_ = [("eps", ctypes.c_double), ("stall_tol", ctypes.c_double),
                 ("max_iter", ctypes.c_int32),
                 ("not_improved_lim", ctypes.c_int32), ("flags", ctypes.c_uint32),
-                ("reserved", ctypes.c_int32)]
+                ("reserved", ctypes.c_int32),
+                ("dyn_id", ctypes.c_int32), ("dyn_T", ctypes.c_int32), ("dyn_dt", ctypes.c_double),
+                ("dyn_x0", ctypes.c_void_p)]
 
 
 DQP_OK = 0
@@ -39,7 +41,10 @@ DQP_MAX_DIM = 64
 # every symbol include/dqp.h declares
 SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termination_bytes",
            "dqp_qp_forward", "dqp_qp_backward", "dqp_mpc_assemble", "dqp_mpc_assemble_backward",
-           "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble", "dqp_al_merit")
+           "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble", "dqp_al_merit",
+           "dqp_dyn_sizes", "dqp_dyn_step", "dqp_dyn_jacobian", "dqp_dyn_forward_dynamics",
+           "dqp_dyn_forward_derivatives")
+DQP_DYN = {"pendulum1l": 1, "cartpole1l": 2, "cartpole2l": 3, "pendulum_euler": 4, "pendulum_dx": 5}
 
 
 class dqp_al_mpc_dims(ctypes.Structure):
@@ -101,6 +106,17 @@ def load():
     lib.dqp_al_assemble.argtypes = [ctypes.POINTER(dqp_al_mpc_dims)] + [_dp] * 8
     lib.dqp_al_merit.restype = ctypes.c_int
     lib.dqp_al_merit.argtypes = [ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int32] + [_dp] * 11
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    lib.dqp_dyn_sizes.restype = ctypes.c_int
+    lib.dqp_dyn_sizes.argtypes = [ctypes.c_int, i32p, i32p]
+    lib.dqp_dyn_step.restype = ctypes.c_int
+    lib.dqp_dyn_step.argtypes = [ctypes.c_int, ctypes.c_int32, _dp, _dp, ctypes.c_double, _dp, _dp]
+    lib.dqp_dyn_jacobian.restype = ctypes.c_int
+    lib.dqp_dyn_jacobian.argtypes = [ctypes.c_int, ctypes.c_int32, _dp, _dp, ctypes.c_double] + [_dp] * 4
+    lib.dqp_dyn_forward_dynamics.restype = ctypes.c_int
+    lib.dqp_dyn_forward_dynamics.argtypes = [ctypes.c_int, ctypes.c_int32] + [_dp] * 7
+    lib.dqp_dyn_forward_derivatives.restype = ctypes.c_int
+    lib.dqp_dyn_forward_derivatives.argtypes = [ctypes.c_int, ctypes.c_int32] + [_dp] * 11
     _lib = lib
     return lib
 

@@ -23,7 +23,9 @@
 #include "../../include/dqp.h"
 #include "dqp_r16_prims.h"   // row_sum (DPP row reduction)
 
+#ifdef DQP_STAMPS
 namespace dqp { extern unsigned long long *g_debug_stamps; }
+#endif
 
 namespace {
 
@@ -401,7 +403,11 @@ int fill(const dqp_al_dims *d, AlP &P, size_t &lds)
     if (!d || d->nbatch < 0 || d->nz <= 0 || d->ncon < 0) return DQP_ERR_BAD_ARG;
     if (d->nz > 128) return DQP_ERR_TOO_LARGE;
     P.B = d->nbatch; P.nz = d->nz; P.ncon = d->ncon;
+#ifdef DQP_STAMPS
     P.stamps = dqp::g_debug_stamps;
+#else
+    P.stamps = nullptr;
+#endif
     // LDS: the nz x nz factor (ld = nz | 1: 80,800 B at nz = 100, so two problems share a CU); the
     // same region first stages Jc in chunks of `chunk_rows` zero-padded rows of 16*ceil(nz/16).
     P.ld = d->nz | 1;                 // odd leading dimension: conflict-free column reads

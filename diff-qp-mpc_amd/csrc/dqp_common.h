@@ -30,23 +30,42 @@ struct KParams {
     double *hist;          // pass 1: (B, histIters, 2) = (resid, mu) per iteration, or NULL
     const int32_t *cap;    // pass 2: cap[0] = iteration cap, cap[TERM_HDR + qp] = re-solve this QP
     int histIters;
+    // true-dynamics equality residual (dqp_opts.dyn_*): registered model evaluated per iteration
+    int dynId, dynT, dynN, dynM;
+    double dynDt;
+    const double *dynX0;
 };
 
 constexpr int TERM_HDR = 8;   // int32 header words in front of the redo list
 
-// Record one iteration of a problem's residual history (one lane per problem calls this).
+// Termination buffer (dqp_termination_bytes), see dqp_term.hip: hist [histIters][B] x (resid, mu),
+// then TERM_ACC_BYTES of accumulators + header, then the redo list.
+constexpr int TERM_MAXIT = 64;
+constexpr int TERM_ACC_BYTES = 3 * 8 + TERM_HDR * 4;
+
+// Record one iteration of a problem's residual history (one lane per problem calls this);
+// iteration-major so that the batch reduction reads it coalesced.
 __device__ __forceinline__ void hist_put(const KParams &P, long long qp, int it, double resid, double mu)
 {
-    double2 *h = reinterpret_cast<double2 *>(P.hist) + qp * P.histIters + it;
+    double2 *h = reinterpret_cast<double2 *>(P.hist) + (long long)it * P.B + qp;
     *h = make_double2(resid, mu);
 }
 // The problem left the loop after `iters` iterations: the rest of its history is NaN (what the
 // reference's iterate is from there on: a non-finite residual never recovers, batch.py:119-131).
 __device__ __forceinline__ void hist_fill(const KParams &P, long long qp, int iters)
 {
-    double2 *h = reinterpret_cast<double2 *>(P.hist) + qp * P.histIters;
     const double nan = __builtin_nan("");
-    for (int it = iters; it < P.histIters; ++it) h[it] = make_double2(nan, nan);
+    for (int it = iters; it < P.histIters; ++it)
+        reinterpret_cast<double2 *>(P.hist)[(long long)it * P.B + qp] = make_double2(nan, nan);
+}
+// Pass 1 clears the batch reduction's accumulators itself (the reduction runs after this kernel
+// on the same stream): saves a memset launch per forward call.
+__device__ __forceinline__ void term_zero_acc(const KParams &P)
+{
+    if (P.hist && blockIdx.x == 0) {
+        unsigned *a = reinterpret_cast<unsigned *>(P.hist + (long long)P.B * P.histIters * 2);
+        for (int i = threadIdx.x; i < TERM_ACC_BYTES / 4; i += blockDim.x) a[i] = 0u;
+    }
 }
 
 // batch rule replay + redo list (dqp_term.hip); 0 on success
@@ -54,7 +73,6 @@ size_t term_bytes(int B, int maxIter);
 int term_decide(const KParams &P, void *term, void *stream);
 void term_bind_pass1(KParams &P, void *term);
 void term_bind_pass2(KParams &P, void *term);
-int term_clear(const KParams &P, void *term, void *stream);
 
 
 // DPP-row kernels (dqp_r16.hip): 4 QPs per wavefront for compile-time sizes <= 32.

@@ -28,6 +28,7 @@
 #include <stdint.h>
 
 #include "dqp_common.h"
+#include "dqp_dyn_models.h"
 
 using namespace dqp;
 
@@ -428,6 +429,48 @@ __device__ __forceinline__ void kkt_xy(const KParams &P, const Lds &S, double rx
     }
 }
 
+// ry = dyn_res(z) with the registered device model (qp_wrapper.py:326-345): z element i on lane i.
+// scratch: N + E doubles of LDS.  Rows: (T-1) n dynamics rows knot-major, then n rows x_0 - x0.
+template <class Map>
+__device__ __forceinline__ void knot_step(const double *zs, int t, int nt, double dt, double *fs)
+{
+    double xs[Map::NX], us[Map::NU], out[Map::NX];
+#pragma unroll
+    for (int k = 0; k < Map::NX; ++k) xs[k] = zs[t * nt + k];
+#pragma unroll
+    for (int k = 0; k < Map::NU; ++k) us[k] = zs[t * nt + Map::NX + k];
+    Map::template step<double>(xs, us, dt, out);
+#pragma unroll
+    for (int k = 0; k < Map::NX; ++k) fs[t * Map::NX + k] = out[k];
+}
+
+__device__ __forceinline__ double true_dyn_res(const KParams &P, double *scratch, double z, int qp, int lane)
+{
+    const int n = P.dynN, m = P.dynM, T = P.dynT, nt = n + m, N = P.N, E = P.E;
+    double *zs = scratch, *fs = scratch + N;
+    WSYNC();
+    if (lane < N) zs[lane] = z;
+    WSYNC();
+    if (lane < T - 1) {
+        switch (P.dynId) {
+        case DQP_DYN_PENDULUM1L: knot_step<dyn::Robot<dyn::Pendulum1l>>(zs, lane, nt, P.dynDt, fs); break;
+        case DQP_DYN_CARTPOLE1L: knot_step<dyn::Robot<dyn::Cartpole1l>>(zs, lane, nt, P.dynDt, fs); break;
+        case DQP_DYN_CARTPOLE2L: knot_step<dyn::Robot<dyn::Cartpole2l>>(zs, lane, nt, P.dynDt, fs); break;
+        case DQP_DYN_PENDULUM_EULER: knot_step<dyn::PendulumEuler>(zs, lane, nt, P.dynDt, fs); break;
+        default: knot_step<dyn::PendulumDx>(zs, lane, nt, P.dynDt, fs); break;
+        }
+    }
+    WSYNC();
+    double ry = 0.0;
+    if (lane < E) {
+        const int t = lane / n, i = lane - t * n;
+        if (t < T - 1) ry = fs[lane] - zs[(t + 1) * nt + i];
+        else if (t == T - 1) ry = zs[i] - P.dynX0[(long long)qp * n + i];
+        else ry = zs[(T - 1) * nt + i];         // add_goal_constraint rows: x_{T-1} - 0 (qp_wrapper.py:339-341,650-652)
+    }
+    return ry;
+}
+
 __device__ __forceinline__ double step_ratio(double v, double dv, bool active)
 {
     // batch.py:211-214: entries with dv > 0 never bind after the min(., 1)
@@ -443,6 +486,7 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
     const Lds S = carve(sm, P);
 
     double rdq, rd1;
+    term_zero_acc(P);
     int maxIter = P.maxIter;
     const bool batch = (P.flags & DQP_FLAG_BATCH_TERMINATION) != 0;
     if (P.cap) {        // pass 2 of the batch rule: only the listed QPs, up to the reference's stop
@@ -481,16 +525,22 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
     for (int it = 0; it < maxIter; ++it) {
         // residuals in hat coordinates                                   batch.py:93-108
         double rxh = xh + ph + matvecT<MAXM>(S.Gh, P.ldz, M, N, z, lane);
-        double ryt = 0.0;
+        double ryt = 0.0, ry = 0.0;
         if (E > 0) {
             rxh += matvecT<MAXM>(S.At, P.ldz, E, N, yt, lane);
-            ryt = matvec<MAXM>(S.At, P.ldz, E, N, xh, lane) - bt;
+            if (P.dynId) {      // ry = dyn_res(x) with the true model; the Newton rhs is L1^-1 ry
+                const double x = trsv_LT(S.Lq, P.ldz, N, xh, rdq, lane);
+                ry = true_dyn_res(P, S.T + (size_t)M * P.ldt, x, qp, lane);
+                ryt = trsv_L(S.L1, P.lde, E, ry, rd1, lane);
+                ryt = inE ? ryt : 0.0;
+            } else {
+                ryt = matvec<MAXM>(S.At, P.ldz, E, N, xh, lane) - bt;
+                ry = trimatvec<MAXM>(S.L1, P.lde, E, ryt, lane);
+            }
         }
         const double gx = matvec<MAXM>(S.Gh, P.ldz, M, N, xh, lane);
         const double rz = inM ? gx + s - hh : 0.0;
         const double rx = trimatvec<MAXM>(S.Lq, P.ldz, N, rxh, lane);       // rx = Lq rxh
-        double ry = 0.0;
-        if (E > 0) ry = trimatvec<MAXM>(S.L1, P.lde, E, ryt, lane);
         const double sz = wave_sum(inM ? s * z : 0.0);
         const double mu = fabs(sz / M);
         const double resid = sqrt(wave_sum(rz * rz)) + sqrt(wave_sum(ry * ry)) +
@@ -643,9 +693,20 @@ int fill_params(const dqp_dims *d, const dqp_opts *o, KParams &P, size_t &lds_by
     P.notImprovedLim = o ? o->not_improved_lim : 3;
     P.flags = o ? o->flags : 0u;
     P.hist = nullptr; P.cap = nullptr; P.histIters = P.maxIter;
+    P.dynId = o ? o->dyn_id : 0;
+    P.dynT = 0; P.dynN = 0; P.dynM = 0; P.dynDt = 0.0; P.dynX0 = nullptr;
+    if (P.dynId) {
+        int32_t n = 0, m = 0;
+        if (dqp_dyn_sizes(P.dynId, &n, &m) != DQP_OK) return DQP_ERR_BAD_ARG;
+        P.dynT = o->dyn_T; P.dynN = n; P.dynM = m; P.dynDt = o->dyn_dt; P.dynX0 = o->dyn_x0;
+        if (P.dynT < 2 || P.dynT > WAVE || P.N != P.dynT * (n + m) ||
+            (P.E != P.dynT * n && P.E != (P.dynT + 1) * n) || !P.dynX0)
+            return DQP_ERR_BAD_ARG;
+    }
     size_t n = (size_t)P.N * P.ldz + (size_t)P.M * P.ldz + (size_t)P.E * P.ldz +
                (size_t)P.E * P.lde + (size_t)P.M * (P.ldm > P.lde ? P.ldm : P.lde) +
                (size_t)P.M * P.ldt;
+    if (P.dynId) n += (size_t)P.N + P.E;        // true_dyn_res scratch behind the T buffer
     lds_bytes = n * sizeof(double);
     if (lds_bytes > 160 * 1024) return DQP_ERR_TOO_LARGE;
     return DQP_OK;
@@ -735,10 +796,9 @@ dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, cons
     //   2. the batch rule is evaluated on that history -> the iteration the reference stops at,
     //      and the list of problems whose best iterate came after it;
     //   3. those problems (none in a large batch) are solved again up to that iteration.
-    // Five enqueues on `stream`, no host synchronisation, hipGraph-capturable.
+    // Three enqueues on `stream`, no host synchronisation, hipGraph-capturable.
     if (!termination || P.maxIter < 1 || P.maxIter > 64) return DQP_ERR_BAD_ARG;
     P.eps = opts ? opts->eps : 1e-12;            // the batch rule uses the reference's eps itself
-    if ((rc = term_clear(P, termination, stream)) != DQP_OK) return rc;
     term_bind_pass1(P, termination);
     if ((rc = forward_once(P, lds, workspace, stream)) != DQP_OK) return rc;
     if ((rc = term_decide(P, termination, stream)) != DQP_OK) return rc;
@@ -749,7 +809,7 @@ dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, cons
 static int forward_once(const KParams &P, size_t lds, void *workspace, void *stream)
 {
     int rc;
-    if (!(P.flags & DQP_FLAG_GENERIC_ONLY)) {
+    if (!(P.flags & DQP_FLAG_GENERIC_ONLY) && !P.dynId) {
         // DPP-row kernels for the instantiated sizes: the null-space form when the caller gave
         // it its workspace (and did not opt out), else the form that keeps the equality rows.
         rc = (workspace && !(P.flags & DQP_FLAG_NO_NULLSPACE)) ? r16n_forward(P, stream) : 1;

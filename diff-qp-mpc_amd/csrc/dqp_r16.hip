@@ -281,6 +281,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     }
     double *lds = sm + qrow * C::ldsQPpad;
 
+    term_zero_acc(P);
     State<C> st;
     setup<C>(P, qp, r, lds, st);
 

@@ -107,6 +107,20 @@ __device__ __forceinline__ double frsqrt(double d)
     } while (0)
 #endif
 
+#if defined(DQP_STAMPS_C)     /* experiment: the 16 slots record the reflector loop of the null-space setup */
+#undef STAMP
+#define STAMP(P, i) do { } while (0)
+#define STAMPC(P, i)                                                                 \
+    do {                                                                             \
+        if ((P).stamps) {                                                            \
+            __builtin_amdgcn_sched_barrier(0);                                       \
+            const unsigned long long t__ = __builtin_readcyclecounter();             \
+            if (threadIdx.x == 0) (P).stamps[blockIdx.x * 16 + (i)] = t__;           \
+            __builtin_amdgcn_sched_barrier(0);                                       \
+        }                                                                            \
+    } while (0)
+#endif
+
 constexpr __host__ __device__ int slots(int n) { return (n + 15) / 16; }
 constexpr __host__ __device__ int tri(int i) { return i * (i + 1) / 2; }
 

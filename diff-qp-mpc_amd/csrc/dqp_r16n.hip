@@ -288,6 +288,9 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
 #pragma unroll
         for (int k = E - 1; k >= 0; --k) {
             const int sk = k >> 4, lk = k & 15, ck = R + k;
+#ifdef DQP_STAMPS_C      /* experiment: one stamp per reflector */
+            if (k < 15) { STAMPC(P, k); }
+#endif
             double u[N];
             double nrm2 = 0.0;
 #pragma unroll
@@ -335,6 +338,9 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
                 st.Gh[s][ck] -= tw;
             }
         }
+#ifdef DQP_STAMPS_C
+        STAMPC(P, 15);
+#endif
         __syncthreads();          // tails are read back as distributed vectors
         __builtin_amdgcn_sched_barrier(0);
 
@@ -563,6 +569,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     double *lds = sm + qrow * C::ldsQPpad;
     double *dummy = lds + C::oDummy + r;
 
+    term_zero_acc(P);
     State<C> st;
     STAMP(P, 0);
     setup<C>(P, qp, r, lds, st);

@@ -11,87 +11,101 @@
 // at an iteration >= I* -- they are solved again with max_iter = I* (pass 2).  In a large batch
 // some sample improves at every iteration, I* = max_iter and pass 2 is an empty launch.
 //
-// Buffer layout (dqp_termination_bytes): hist (B, maxIter) x {resid, mu} doubles | accumulators:
-// u64 bestmax[64], u64 mumin_c[64], u64 improved, u64 bestnan, u64 munan | int32 header[TERM_HDR]
-// (header[0] = I*, header[1] = number of problems to redo) then int32 redo[B] (pass 1 stores the
-// problem's best iteration there, term_decide_kernel turns it into the flag).
+// Buffer layout (dqp_termination_bytes): hist (maxIter, B) x {resid, mu} doubles | accumulators:
+// three u64 masks (improved, notbelow, notabove: one bit per iteration) | int32 header[TERM_HDR]
+// (header[0] = I*, header[1] = number of problems to redo, header[2] = block arrival counter) then
+// int32 redo[B] (the scan stores the problem's best iteration there, its last block the flag).
+// Pass 1 zeroes accumulators + header itself (term_zero_acc), so a forward call is three launches.
 #include "dqp_common.h"
 
 namespace dqp {
 
 namespace {
 
-constexpr int MAXIT = 64;
+constexpr int MAXIT = TERM_MAXIT;
+// The three batch-wide tests of the rule are ANDs / ORs of per-sample predicates, so each sample
+// contributes one bit per iteration and the batch reduction is an OR of 64-bit masks:
 struct Acc {
-    unsigned long long bestmax[MAXIT];   // max over the batch of best_resids after iteration it (bit pattern)
-    unsigned long long mumin_c[MAXIT];   // ~bits of min over the batch of mu at iteration it
-    unsigned long long improved;         // bit it: some sample improved at iteration it
-    unsigned long long bestnan;          // bit it: some sample's best residual is NaN (=> .max() is NaN)
-    unsigned long long munan;            // bit it: some sample's mu is NaN (=> .min() is NaN)
+    unsigned long long improved;   // bit it: some sample improved at iteration it
+    unsigned long long notbelow;   // bit it: some sample has NOT best_resid < eps (=> .max() < eps fails;
+                                   //         a NaN best residual lands here, as torch's NaN max does)
+    unsigned long long notabove;   // bit it: some sample has NOT mu > 1e32 (=> mu.min() > 1e32 fails)
 };
+static_assert(sizeof(Acc) + TERM_HDR * sizeof(int32_t) == TERM_ACC_BYTES, "layout shared with dqp_common.h");
 
 inline size_t hist_bytes(int B, int maxIter) { return (size_t)B * maxIter * 2 * sizeof(double); }
 
-__global__ __launch_bounds__(256) void term_scan_kernel(const double2 *hist, Acc *acc, int32_t *argbest,
-                                                        int B, int maxIter)
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
 {
-    __shared__ unsigned long long s_max[MAXIT], s_min[MAXIT], s_imp, s_bn, s_mn;
-    const int tid = threadIdx.x;
-    if (tid < MAXIT) { s_max[tid] = 0ull; s_min[tid] = 0ull; }
-    if (tid == 0) { s_imp = 0ull; s_bn = 0ull; s_mn = 0ull; }
-    __syncthreads();
-    const long long qp = (long long)blockIdx.x * blockDim.x + tid;
-    if (qp < B) {
-        const double2 *h = hist + qp * maxIter;
-        double best = 0.0;
-        int arg = 0;
-        unsigned long long imp = 0ull, bn = 0ull, mn = 0ull;
-        for (int it = 0; it < maxIter; ++it) {
-            const double2 v = h[it];
-            if (it == 0) { best = v.x; }                           // batch.py:120-126
-            else if (v.x < best) { best = v.x; arg = it; imp |= 1ull << it; }
-            if (best != best) bn |= 1ull << it;
-            else atomicMax(&s_max[it], (unsigned long long)__double_as_longlong(best));
-            if (v.y != v.y) mn |= 1ull << it;
-            else atomicMax(&s_min[it], ~(unsigned long long)__double_as_longlong(v.y));
-        }
-        argbest[qp] = arg;
-        if (imp) atomicOr(&s_imp, imp);
-        if (bn) atomicOr(&s_bn, bn);
-        if (mn) atomicOr(&s_mn, mn);
-    }
-    __syncthreads();
-    if (tid < maxIter) {
-        atomicMax(&acc->bestmax[tid], s_max[tid]);
-        atomicMax(&acc->mumin_c[tid], s_min[tid]);
-    }
-    if (tid == 0) {
-        if (s_imp) atomicOr(&acc->improved, s_imp);
-        if (s_bn) atomicOr(&acc->bestnan, s_bn);
-        if (s_mn) atomicOr(&acc->munan, s_mn);
-    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v |= __shfl_xor(v, off, 64);
+    return v;
 }
 
-__global__ __launch_bounds__(256) void term_decide_kernel(const Acc *acc, int32_t *hdr, int B, int maxIter,
-                                                          int notImprovedLim, double eps)
+// One thread per problem walks its history (best-so-far, the iteration it was found at) and
+// collects its three masks; one OR-reduction per wavefront, one atomicOr per block.  The last block
+// to finish replays the reference's rule on the masks and writes I* and the redo flags
+// (hdr[0], hdr[1], hdr[TERM_HDR + qp]; hdr[2] is the arrival counter).
+__global__ __launch_bounds__(256) void term_scan_kernel(const double2 *hist, Acc *acc, int32_t *hdr,
+                                                        int B, int maxIter, int notImprovedLim, double eps)
 {
-    // every thread replays the (<= 64-step) batch rule; cheaper than a second launch
-    int istop = maxIter, nNot = 0;
-    const unsigned long long imp = acc->improved, bn = acc->bestnan, mn = acc->munan;
-    for (int it = 0; it < maxIter; ++it) {
-        if (it == 0 || ((imp >> it) & 1ull)) nNot = 0;
-        else nNot += 1;
-        const bool best_ok = !((bn >> it) & 1ull) && __longlong_as_double((long long)acc->bestmax[it]) < eps;
-        const bool mu_ok = !((mn >> it) & 1ull) && __longlong_as_double((long long)~acc->mumin_c[it]) > 1e32;
-        if (nNot == notImprovedLim || best_ok || mu_ok) { istop = it + 1; break; }
+    __shared__ unsigned long long s_m[3][4];
+    __shared__ int s_last, s_istop;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long qp = (long long)blockIdx.x * blockDim.x + tid;
+    const bool live = qp < B;
+    int32_t *argbest = hdr + TERM_HDR;
+    unsigned long long imp = 0ull, nb = 0ull, na = 0ull;
+    if (live) {
+        const double2 *h = hist + qp;
+        double best = 0.0;
+        int arg = 0;
+        for (int it = 0; it < maxIter; ++it) {
+            const double2 v = h[(long long)it * B];
+            if (it == 0) best = v.x;                                   // batch.py:120-126
+            else if (v.x < best) { best = v.x; arg = it; imp |= 1ull << it; }
+            if (!(best < eps)) nb |= 1ull << it;
+            if (!(v.y > 1e32)) na |= 1ull << it;
+        }
+        argbest[qp] = arg;
     }
-    const long long qp = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (qp < B) {
-        const int redo = hdr[TERM_HDR + qp] >= istop ? 1 : 0;
-        hdr[TERM_HDR + qp] = redo;
-        if (redo) atomicAdd(&hdr[1], 1);
+    imp = wave_or_u64(imp); nb = wave_or_u64(nb); na = wave_or_u64(na);
+    if (lane == 0) { s_m[0][wave] = imp; s_m[1][wave] = nb; s_m[2][wave] = na; }
+    __syncthreads();
+    if (tid < 3) {
+        const unsigned long long m = s_m[tid][0] | s_m[tid][1] | s_m[tid][2] | s_m[tid][3];
+        unsigned long long *dst = tid == 0 ? &acc->improved : (tid == 1 ? &acc->notbelow : &acc->notabove);
+        if (m) atomicOr(dst, m);
     }
-    if (qp == 0) hdr[0] = istop;
+    // ---- last block: the rule itself
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(&hdr[2], 1) == (int)gridDim.x - 1);
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid == 0) {
+        const unsigned long long ai = __hip_atomic_load(&acc->improved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long anb = __hip_atomic_load(&acc->notbelow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long ana = __hip_atomic_load(&acc->notabove, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int istop = maxIter, nNot = 0;
+        for (int it = 0; it < maxIter; ++it) {
+            if (it == 0 || ((ai >> it) & 1ull)) nNot = 0;
+            else nNot += 1;
+            if (nNot == notImprovedLim || !((anb >> it) & 1ull) || !((ana >> it) & 1ull)) { istop = it + 1; break; }
+        }
+        s_istop = istop;
+        hdr[0] = istop;
+    }
+    __syncthreads();
+    const int istop = s_istop;
+    int nredo = 0;
+    for (long long q = tid; q < B; q += blockDim.x) {
+        const int redo = __hip_atomic_load(&argbest[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= istop ? 1 : 0;
+        argbest[q] = redo;
+        nredo += redo;
+    }
+    if (nredo) atomicAdd(&hdr[1], nredo);
 }
 
 inline Acc *acc_of(void *term, int B, int maxIter) { return (Acc *)((char *)term + hist_bytes(B, maxIter)); }
@@ -103,13 +117,6 @@ size_t term_bytes(int B, int maxIter)
 {
     if (B <= 0 || maxIter <= 0) return 0;
     return hist_bytes(B, maxIter) + sizeof(Acc) + (size_t)(TERM_HDR + B) * sizeof(int32_t);
-}
-
-int term_clear(const KParams &P, void *term, void *stream)
-{
-    // accumulators and header to zero (hist and the redo list are fully overwritten by pass 1 / scan)
-    return hipMemsetAsync(acc_of(term, P.B, P.maxIter), 0, sizeof(Acc) + TERM_HDR * sizeof(int32_t),
-                          (hipStream_t)stream) == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
 void term_bind_pass1(KParams &P, void *term)
@@ -128,12 +135,9 @@ void term_bind_pass2(KParams &P, void *term)
 int term_decide(const KParams &P, void *term, void *stream)
 {
     const int blocks = (P.B + 255) / 256;
-    Acc *acc = acc_of(term, P.B, P.maxIter);
-    int32_t *hdr = hdr_of(term, P.B, P.maxIter);
     hipLaunchKernelGGL(term_scan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const double2 *)term, acc, hdr + TERM_HDR, P.B, P.maxIter);
-    hipLaunchKernelGGL(term_decide_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const Acc *)acc, hdr, P.B, P.maxIter, P.notImprovedLim, P.eps);
+                       (const double2 *)term, acc_of(term, P.B, P.maxIter), hdr_of(term, P.B, P.maxIter),
+                       P.B, P.maxIter, P.notImprovedLim, P.eps);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 

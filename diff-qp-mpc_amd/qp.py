@@ -2,9 +2,12 @@
 computed by the fused HIP kernels behind the C ABI (include/dqp.h).
 
 Differences from the reference, all documented in DESIGN.md:
-  * `dyn_res` / `cost_grad` are accepted positionally (qp.py:24) but the fused kernel
-    evaluates the linear forms dyn_res(x) = A x - b and cost_grad(x) = Q x + p on chip;
-    pass `check_callables=True` to verify a supplied closure against them at one point.
+  * `dyn_res` / `cost_grad` are accepted positionally (qp.py:24).  The fused kernel evaluates
+    cost_grad(x) = Q x + p and, for dyn_res, either the linear form A x - b or -- when dyn_res is a
+    dynamics.DynamicsResidual over a registered device model -- the TRUE-dynamics residual on chip,
+    every iteration, as the reference does with its Python closure (qp_wrapper.py:309,316).  Any
+    other closure is checked against the linear forms at one random point (check_callables=True,
+    the default) and refused if it differs: nothing is substituted silently.
   * termination: the reference's batch-coupled rule (batch.py:119-144) is reproduced on the
     device by default (TERMINATION = "batch"); "per_problem" lets every problem stop on its own
     (include/dqp.h) -- faster in very large batches, float-tolerance parity.
@@ -76,7 +79,7 @@ def _require_gpu(*ts):
                 "There is no CPU fallback." % t.device)
 
 
-def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim, termination=None):
+def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim, termination=None, dyn=None):
     _require_gpu(Q_, p_, G_, h_, A_, b_)
     termination = termination or TERMINATION
     if termination not in ("batch", "per_problem"):
@@ -96,6 +99,11 @@ def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim, terminat
     dims = _lib.dqp_dims(nBatch, nz, nineq, neq, sQ, sp, sG, sh, sA, sb)
     flags = FORCE_FLAGS | (_lib.DQP_FLAG_BATCH_TERMINATION if termination == "batch" else 0)
     opts = _lib.dqp_opts(eps, STALL_TOL, maxIter, notImprovedLim, flags, 0)
+    if dyn is not None:          # true-dynamics residual on chip (include/dqp.h: dqp_opts.dyn_*)
+        if dyn.x0.shape[0] != nBatch or dyn.x0.device != dev:
+            raise RuntimeError("DynamicsResidual.x0 must be (nBatch, n_state) on the QP's device")
+        opts.dyn_id, opts.dyn_T, opts.dyn_dt = dyn.dynamics.id, dyn.T, dyn.dynamics.dt
+        opts.dyn_x0 = dyn.x0.data_ptr()
     kw = dict(dtype=torch.float64, device=dev)
     zhat = torch.empty(nBatch, nz, **kw)
     lam = torch.empty(nBatch, nineq, **kw)
@@ -115,7 +123,9 @@ def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim, terminat
                                 _stream(dev))
     _lib.check(rc, "dqp_qp_forward")
     # the workspace now holds the factorisation context backward can restart from (include/dqp.h)
-    ctx_ws = ws if (ws is not None and not (FORCE_FLAGS & (_lib.DQP_FLAG_NO_NULLSPACE | _lib.DQP_FLAG_GENERIC_ONLY))) else None
+    # (only the null-space kernels leave one: not the forced families, not the true-dynamics path)
+    ctx_ws = ws if (ws is not None and dyn is None and
+                    not (FORCE_FLAGS & (_lib.DQP_FLAG_NO_NULLSPACE | _lib.DQP_FLAG_GENERIC_ONLY))) else None
     return zhat, lam, nu, slack, info, resid, (Q, G, A, dims, ctx_ws)
 
 
@@ -155,11 +165,20 @@ def _check_callables(Q, p, A, b, dyn_res, cost_grad, nBatch):
         Ae, _ = expandParam(A, nBatch, 3)
         want = torch.bmm(Ae, x.unsqueeze(-1)).squeeze(-1) - b
         if not torch.allclose(dyn_res(x), want, rtol=1e-8, atol=1e-10):
-            raise RuntimeError("dyn_res(x) != Ax - b: only the linear form is fused on chip")
+            raise RuntimeError("dyn_res(x) != Ax - b: a nonlinear residual is fused on chip only for "
+                               "registered device models (pass a dynamics.DynamicsResidual)")
+
+
+def _split_dyn_res(dyn_res):
+    """-> (DynamicsResidual for the fused path or None, closure that still needs the linearity check)"""
+    from .dynamics import DynamicsResidual
+    if isinstance(dyn_res, DynamicsResidual):
+        return dyn_res, None
+    return None, dyn_res
 
 
 def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3, maxIter=20,
-               solver=QPSolvers.PDIPM_BATCHED, check_Q_spd=True, check_callables=False):
+               solver=QPSolvers.PDIPM_BATCHED, check_Q_spd=True, check_callables=True):
     """Factory with the reference's signature (qpth/qp.py:19-21); returns a callable
     `(Q, p, G, h, A, b, dyn_res=None, cost_grad=None) -> zhat (nBatch, nz)`."""
     if solver != QPSolvers.PDIPM_BATCHED:
@@ -169,10 +188,11 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3, maxIter=20,
         @staticmethod
         def forward(ctx, Q_, p_, G_, h_, A_, b_, dyn_res=None, cost_grad=None):
             nBatch = extract_nBatch(Q_, p_, G_, h_, A_, b_)
-            if check_callables:
-                _check_callables(Q_, p_, A_, b_, dyn_res, cost_grad, nBatch)
+            dyn, closure = _split_dyn_res(dyn_res)
+            if check_callables and (closure is not None or cost_grad is not None):
+                _check_callables(Q_, p_, A_, b_, closure, cost_grad, nBatch)
             zhat, lam, nu, slack, info, resid, saved = _forward_impl(
-                Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim)
+                Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim, dyn=dyn)
             if check_Q_spd:
                 st = info[:, 0]
                 if bool((st == _lib.DQP_STATUS_Q_NOT_PD).any()):
@@ -209,7 +229,7 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3, maxIter=20,
     return apply
 
 
-def DenseQPFunction(bsz=1, eps=1e-12, verbose=0, notImprovedLim=3, maxIter=20):
+def DenseQPFunction(bsz=1, eps=1e-12, verbose=0, notImprovedLim=3, maxIter=20, check_callables=True):
     """Factory with the reference's signature (qpth/qp.py:187-188); returns a callable
     `(Q, p, G, h, A, b, dyn_res, cost_grad=None) -> zhat`.  All six parameters must be
     batched (the reference's preprocess(), qp.py:195-217, does no expandParam).
@@ -225,8 +245,11 @@ def DenseQPFunction(bsz=1, eps=1e-12, verbose=0, notImprovedLim=3, maxIter=20):
             for t, nd in zip((Q, p, G, h, A, b), (3, 2, 3, 2, 3, 2)):
                 if t.dim() != nd:
                     raise RuntimeError("DenseQPFunction needs batched parameters")
+            dyn, closure = _split_dyn_res(dyn_res)
+            if check_callables and (closure is not None or cost_grad is not None):
+                _check_callables(Q, p, A, b, closure, cost_grad, Q.shape[0])
             zhat, lam, nu, slack, info, resid, saved = _forward_impl(
-                Q, p, G, h, A, b, eps, maxIter, notImprovedLim)
+                Q, p, G, h, A, b, eps, maxIter, notImprovedLim, dyn=dyn)
             ctx.saved = saved
             ctx.lams, ctx.nus, ctx.slacks, ctx.info = lam, nu, slack, info
             ctx.out_dtype = Q.dtype

@@ -14,10 +14,12 @@ What runs where:
     598-611, 690-692): vectorised torch ops on the same device (they call user-supplied Python
     dynamics, which cannot be fused).
 
-Difference from the reference: it passes the TRUE-dynamics residual closure into the PDIPM
-(`dyn_res_lam`, qp_wrapper.py:309,316); the fused kernel evaluates the residual of the
-LINEARISED dynamics, A z - b.  For LinDx the two are identical (this is what the parity tests
-pin); for nonlinear dynamics they differ inside the QP iterations only.
+The reference passes the TRUE-dynamics residual closure into the PDIPM (`dyn_res_lam`,
+qp_wrapper.py:309,316).  Here: for LinDx that residual IS A z - b (what the kernels evaluate); for
+a dynamics.DeviceDynamics (registered device model) the fused PDIPM evaluates the true residual
+on chip every iteration, like the reference; any other dynamics module is refused unless the
+caller opts into the linearised residual (`linearised_residual=True`, an extension) -- nothing is
+substituted silently.
 """
 import ctypes
 from enum import Enum
@@ -28,6 +30,7 @@ from torch.autograd import Function
 from torch.nn import Module
 
 from . import _lib
+from .dynamics import DeviceDynamics, DynamicsResidual
 from .qp import DenseQPFunction
 
 
@@ -138,7 +141,8 @@ class MPC(Module):
                  linesearch_decay=0.2, max_linesearch_iter=10, exit_unconverged=True,
                  detach_unconverged=True, backprop=True, slew_rate_penalty=None, prev_ctrl=None,
                  not_improved_lim=5, best_cost_eps=1e-4, solver_type='dense',
-                 single_qp_solve=False, add_goal_constraint=False, x_goal=None):
+                 single_qp_solve=False, add_goal_constraint=False, x_goal=None,
+                 linearised_residual=False):
         given = dict(locals())
         super().__init__()
         if (u_lower is None) != (u_upper is None):
@@ -152,7 +156,8 @@ class MPC(Module):
         plain = ("n_state", "n_ctrl", "T", "qp_iter", "grad_method", "delta_u", "verbose", "eps",
                  "back_eps", "n_batch", "linesearch_decay", "max_linesearch_iter", "exit_unconverged",
                  "detach_unconverged", "backprop", "slew_rate_penalty", "prev_ctrl", "not_improved_lim",
-                 "best_cost_eps", "solver_type", "single_qp_solve", "add_goal_constraint", "x_goal")
+                 "best_cost_eps", "solver_type", "single_qp_solve", "add_goal_constraint", "x_goal",
+                 "linearised_residual")
         for name in plain:
             setattr(self, name, given[name])
         for name in ("u_lower", "u_upper", "u_zero_I", "u_init", "x_init"):
@@ -208,12 +213,28 @@ class MPC(Module):
     # ------------------------------------------------------------------ behaviour of qp_wrapper.py:298-324
     def single_qp(self, x, u, dx, dx_jac, x0, cost):
         """One QP around (x, u): returns the step (dx, du) to the QP solution and its cost."""
+        if self.add_goal_constraint and self.x_goal is not None and bool((torch.as_tensor(self.x_goal) != 0).any()):
+            # the reference pins the last state to ZERO in b (qp_wrapper.py:650-652) while its dyn_res
+            # subtracts self.x_goal (:339-341): inconsistent unless the goal is zero
+            raise NotImplementedError("add_goal_constraint with a nonzero x_goal is inconsistent in the "
+                                      "reference (b uses 0, dyn_res uses x_goal); only x_goal = 0 is supported")
+        dyn_res = None
         if isinstance(dx, LinDx):
             F = dx.F
             f = dx.f if dx.f is not None else torch.zeros(self.T - 1, self.n_batch, self.n_state,
                                                           dtype=x0.dtype, device=x0.device)
+            if not isinstance(self.dx_true, LinDx):
+                raise NotImplementedError("dx_true must be the LinDx itself when dx is a LinDx")
         else:
             F, f = self.linearize_dynamics(x, detach_maybe(u), dx, dx_jac, diff=False)
+            if isinstance(self.dx_true, DeviceDynamics):        # the reference's dyn_res_lam, on chip
+                dyn_res = DynamicsResidual(self.dx_true, x0, self.T, goal_rows=self.add_goal_constraint)
+            elif not self.linearised_residual:
+                raise NotImplementedError(
+                    "qp_wrapper.MPC evaluates the true-dynamics residual inside the QP iterations "
+                    "(reference qp_wrapper.py:309,316); that is fused on chip for registered device "
+                    "models only (dynamics.DeviceDynamics).  Pass linearised_residual=True to solve with "
+                    "the residual of the linearised dynamics instead.")
         ul = uu = None
         if self.u_upper is not None:
             as_t = lambda v: (torch.full((self.n_ctrl,), float(v), dtype=torch.float64, device=x0.device)
@@ -230,7 +251,7 @@ class MPC(Module):
             Ag[:, ar, (self.T - 1) * nt + ar] = 1.0
             A = torch.cat([A, Ag], 1)
             b = torch.cat([b, torch.zeros(self.n_batch, n, dtype=b.dtype, device=b.device)], 1)
-        tau = DenseQPFunction()(Q, q, G, h, A, b, None).to(x0.dtype).reshape(self.n_batch, self.T, -1)
+        tau = DenseQPFunction()(Q, q, G, h, A, b, dyn_res).to(x0.dtype).reshape(self.n_batch, self.T, -1)
         x_qp, u_qp = tau[..., :self.n_state].transpose(0, 1), tau[..., self.n_state:].transpose(0, 1)
         return x_qp - x, u_qp - u, self.compute_cost(tau, cost)
 
@@ -289,8 +310,13 @@ class MPC(Module):
     # ------------------------------------------------------------------ behaviour of qp_wrapper.py:481-515
     def linearize_dynamics(self, x, u, dynamics, dx_jac, diff):
         """First-order model of `dynamics` along (x, u): F_t = [df/dx, df/du], f_t = f(x_t,u_t) - F_t tau_t."""
-        if self.grad_method != GradMethods.ANALYTIC:
-            raise NotImplementedError("only GradMethods.ANALYTIC (dx_jac) is mirrored")
+        if self.grad_method == GradMethods.FINITE_DIFF:
+            return self._linearize_fd(x, u, dynamics)
+        if self.grad_method not in (GradMethods.ANALYTIC, GradMethods.AUTO_DIFF):
+            raise NotImplementedError("GradMethods.ANALYTIC_CHECK is disabled in the reference too "
+                                      "(`assert False # Not updated`, qp_wrapper.py:549)")
+        # ANALYTIC and AUTO_DIFF both read the Jacobians from dx_jac (qp_wrapper.py:497,547); the
+        # reference's AUTO_DIFF branch only differs by looping over time steps
         n_batch = x.shape[1]
         xs = x[:-1].reshape(-1, self.n_state)
         us = u[:-1].reshape(-1, self.n_ctrl)
@@ -302,6 +328,22 @@ class MPC(Module):
         f = nxt - bmv(F, torch.cat((xs, us), dim=1))
         return (F.reshape(self.T - 1, n_batch, self.n_state, self.n_state + self.n_ctrl),
                 f.reshape(self.T - 1, n_batch, self.n_state))
+
+    def _linearize_fd(self, x, u, dynamics, eps=1e-4):
+        """GradMethods.FINITE_DIFF (qp_wrapper.py:561-576, util.jacobian with eps 1e-4): central
+        differences of the dynamics, evaluated as one batch of 2 (n + m) perturbed copies."""
+        T, B, n, m = self.T, x.shape[1], self.n_state, self.n_ctrl
+        xs, us = x[:-1].reshape(-1, n).detach(), u[:-1].reshape(-1, m).detach()
+        N = xs.shape[0]
+        tau = torch.cat((xs, us), dim=1)
+        E = eps * torch.eye(n + m, dtype=tau.dtype, device=tau.device)
+        plus = (tau[:, None, :] + E[None]).reshape(-1, n + m)
+        minus = (tau[:, None, :] - E[None]).reshape(-1, n + m)
+        fp = dynamics(plus[:, :n], plus[:, n:]).reshape(N, n + m, n)
+        fm = dynamics(minus[:, :n], minus[:, n:]).reshape(N, n + m, n)
+        F = ((fp - fm) / (2 * eps)).transpose(1, 2)
+        f = dynamics(xs, us).detach() - bmv(F, tau)
+        return F.reshape(T - 1, B, n, n + m), f.reshape(T - 1, B, n)
 
     # ------------------------------------------------------------------ behaviour of qp_wrapper.py:598-611
     def rollout(self, x, actions, dynamics):

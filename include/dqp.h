@@ -85,6 +85,18 @@ typedef struct dqp_opts {
     int32_t not_improved_lim; /* qp.py:19  notImprovedLim=3                                */
     uint32_t flags;
     int32_t reserved;
+    /* True-dynamics equality residual (qp_wrapper.py:309,316,326-345 -> batch_LU.py:97 / batch.py:102):
+     * with dyn_id != 0 the PDIPM evaluates ry = dyn_res(z) = [f(x_t,u_t) - x_{t+1}]_{t<T-1}, x_0 - x0
+     * with f the registered device model (DQP_DYN_*, below) instead of A z - b, every iteration, as
+     * the reference does with its Python closure; z is per knot [x_t (n_state), u_t (n_ctrl)], so
+     * nz = dyn_T (n_state + n_ctrl) and neq = dyn_T n_state (+ n_state rows x_{T-1} = 0 of
+     * add_goal_constraint, qp_wrapper.py:339-341).  A and b (the linearisation) still
+     * define the Newton systems and the starting point.  dyn_x0: device pointer (nbatch, n_state).
+     * Runs on the generic one-QP-per-wavefront kernels.  dyn_id == 0: ry = A z - b.                 */
+    int32_t dyn_id;
+    int32_t dyn_T;
+    double dyn_dt;
+    const double *dyn_x0;
 } dqp_opts;
 
 int dqp_version(void);
@@ -246,6 +258,60 @@ int dqp_al_merit(const dqp_al_mpc_dims *dims, int32_t ncand, const double *xu, c
                  const double *x0, const double *Qdiag, const double *q, const double *lam,
                  const double *rho, const double *u_lower, const double *u_upper, double *merit,
                  void *stream);
+
+/* ----------------------------------------------------------------- device dynamics registry */
+
+/*
+ * Robots and pendulum models the reference evaluates through per-robot torch extensions or Python
+ * modules, available to callers (and inlined by the MPC / AL kernels) as device code:
+ *   DQP_DYN_PENDULUM1L / CARTPOLE1L / CARTPOLE2L  deqmpc/my_envs/{pendulum1l,cartpole1l,cartpole2l}
+ *       (CasADi RK4 step of the rigid-body model; state x = [q, qdot], n_state = 2 nq = 2 / 4 / 6,
+ *       the control drives joint 0: deqmpc/my_envs/dynamics.py:26-63)
+ *   DQP_DYN_PENDULUM_EULER   deqmpc/envs.py:5-47 PendulumDynamics (n_state 2, semi-implicit Euler)
+ *   DQP_DYN_PENDULUM_DX      qpth/env_dx/pendulum.py:18-83 PendulumDx, simple=True, default
+ *       parameters (n_state 3: cos th, sin th, thdot; control clamped to +-2)
+ */
+enum {
+    DQP_DYN_PENDULUM1L = 1,
+    DQP_DYN_CARTPOLE1L = 2,
+    DQP_DYN_CARTPOLE2L = 3,
+    DQP_DYN_PENDULUM_EULER = 4,
+    DQP_DYN_PENDULUM_DX = 5
+};
+
+/* n_state / n_ctrl of a registered model; DQP_ERR_BAD_ARG for an unknown id. */
+int dqp_dyn_sizes(int id, int32_t *n_state, int32_t *n_ctrl);
+
+/*
+ * x_next = f(x, u) for n samples: x (n,n_state), u (n,n_ctrl), step dt.
+ * Replaces: Dynamics.forward (deqmpc/my_envs/dynamics.py:26-63), PendulumDynamics.forward
+ *           (deqmpc/envs.py:16-31), PendulumDx.forward (qpth/env_dx/pendulum.py:49-83).
+ */
+int dqp_dyn_step(int id, int32_t n, const double *x, const double *u, double dt, double *x_next,
+                 void *stream);
+
+/*
+ * x_next and the Jacobians Jx (n,n_state,n_state) = d x_next_i / d x_j, Ju (n,n_state,n_ctrl).
+ * Any output may be NULL.  Replaces: Dynamics.dynamics_derivatives / derivatives
+ * (deqmpc/my_envs/dynamics.py:66-112,253-263), PendulumDynamics_jac (deqmpc/envs.py:68-82) -- the
+ * `dx_jac(x, u) -> (x_next, (Jx, Ju))` closure the MPC layers call (qp_wrapper.py:497,
+ * al_utils.py:212-262).
+ */
+int dqp_dyn_jacobian(int id, int32_t n, const double *x, const double *u, double dt, double *x_next,
+                     double *Jx, double *Ju, void *stream);
+
+/*
+ * The reference extension's own interface (deqmpc/my_envs/cartpole1l/src/dynamics_cpu.cpp:8-56,
+ * dynamics_gpu.cu kernels): q, qdot, tau (n,nq), per-sample step h (n); the six Jacobian blocks
+ * are (n,nq,nq) with block[in i][out j], i.e. the raw CasADi buffers the reference's wrapper
+ * concatenates and transposes (dynamics.py:99-112).  Robots 1-3 only.  Any block may be NULL.
+ */
+int dqp_dyn_forward_dynamics(int id, int32_t n, const double *q, const double *qdot, const double *tau,
+                             const double *h, double *q_out, double *qdot_out, void *stream);
+int dqp_dyn_forward_derivatives(int id, int32_t n, const double *q, const double *qdot,
+                                const double *tau, const double *h, double *q_jac_q,
+                                double *q_jac_qdot, double *q_jac_tau, double *qdot_jac_q,
+                                double *qdot_jac_qdot, double *qdot_jac_tau, void *stream);
 
 #ifdef __cplusplus
 }

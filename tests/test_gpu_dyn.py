@@ -1,0 +1,114 @@
+"""GPU parity of the device dynamics registry (include/dqp.h dqp_dyn_*) against
+the golden vectors of tests/golden/DYN_*.npz (the reference's CasADi-generated C for the robots,
+its torch modules for the pendulums; make_golden_dyn.py) and, when oracle/_ref travelled to the box,
+against the reference's compiled C on fresh random states.  Tolerances (absolute, values O(1-10)):
+states 1e-12, Jacobians 1e-11."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dyn_ref
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+NAMES = ["pendulum1l", "cartpole1l", "cartpole2l", "pendulum_euler", "pendulum_dx"]
+
+
+def dev(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float64, device="cuda")
+
+
+@pytest.fixture(scope="module")
+def dynmod():
+    assert torch.cuda.is_available()
+    from diff_qp_mpc_amd import dynamics, _lib
+    _lib.load()
+    return dynamics
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_step_and_jacobian_vs_golden(dynmod, name):
+    g = np.load(os.path.join(GOLDEN, "DYN_%s.npz" % name))
+    dyn = dynmod.DeviceDynamics(name, dt=float(g["dt"]))
+    assert (dyn.n_state, dyn.n_ctrl) == (g["x"].shape[1], g["u"].shape[1])
+    x, u = dev(g["x"]), dev(g["u"])
+    np.testing.assert_allclose(dyn(x, u).cpu().numpy(), g["x_next"], rtol=0, atol=1e-12)
+    xn, (Jx, Ju) = dyn.jac(x, u)
+    np.testing.assert_allclose(xn.cpu().numpy(), g["x_next"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(Jx.cpu().numpy(), g["Jx"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(Ju.cpu().numpy(), g["Ju"], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("name", NAMES[:3])
+def test_extension_interface_vs_golden(dynmod, name):
+    """dynamics(q, qdot, tau, h) / derivatives(...) of deqmpc/my_envs/*: per-sample h, full tau,
+    six raw blocks."""
+    g = np.load(os.path.join(GOLDEN, "DYN_%s.npz" % name))
+    dyn = dynmod.DeviceDynamics(name)
+    q, qd, tau, h = dev(g["q"]), dev(g["qd"]), dev(g["tau"]), dev(g["h"])
+    qo, qdo = dyn.forward_dynamics(q, qd, tau, h)
+    np.testing.assert_allclose(qo.cpu().numpy(), g["q_out"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(qdo.cpu().numpy(), g["qd_out"], rtol=0, atol=1e-12)
+    for i, b in enumerate(dyn.forward_derivatives(q, qd, tau, h)):
+        np.testing.assert_allclose(b.cpu().numpy(), g["blk%d" % i], rtol=0, atol=1e-11, err_msg="block %d" % i)
+
+
+@pytest.mark.parametrize("name", NAMES[:3])
+def test_vs_compiled_reference_full_size(dynmod, name):
+    """B x (T-1) = 4096 x 19 knots (the config-3 Jacobian call): every sample against oracle/_ref."""
+    if not dyn_ref.available(name):
+        pytest.skip("oracle/_ref did not travel")
+    nq = dyn_ref.ROBOTS[name]
+    N = 4096 * 19
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-np.pi, np.pi, (N, nq)), rng.uniform(-8, 8, (N, nq))], 1)
+    u = rng.uniform(-100, 100, (N, 1))
+    dyn = dynmod.DeviceDynamics(name, dt=0.05)
+    xn, (Jx, Ju) = dyn.jac(dev(x), dev(u))
+    sub = rng.choice(N, 4000, replace=False)            # the ctypes reference is per-sample Python
+    ref = dyn_ref.step_x(name, x[sub], u[sub], 0.05)
+    rJx, rJu = dyn_ref.jac_x(name, x[sub], u[sub], 0.05)
+    scale = 1.0 + np.abs(ref).max()
+    np.testing.assert_allclose(xn.cpu().numpy()[sub], ref, rtol=0, atol=1e-12 * scale)
+    np.testing.assert_allclose(Jx.cpu().numpy()[sub], rJx, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(Ju.cpu().numpy()[sub], rJu, rtol=1e-10, atol=1e-10)
+    assert bool(torch.isfinite(xn).all()) and bool(torch.isfinite(Jx).all())
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_autograd_through_the_step(dynmod, name):
+    """DeviceDynamics.forward is differentiable (vector-Jacobian products from the Jacobian kernel):
+    compare with central differences of the kernel itself."""
+    dyn = dynmod.DeviceDynamics(name)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(16, dyn.n_state, dtype=torch.float64, device="cuda", generator=g)
+    if name == "pendulum_dx":
+        x[:, :2] = torch.nn.functional.normalize(x[:, :2], dim=1)
+    u = torch.randn(16, dyn.n_ctrl, dtype=torch.float64, device="cuda", generator=g)
+    w = torch.randn(16, dyn.n_state, dtype=torch.float64, device="cuda", generator=g)
+    xr, ur = x.clone().requires_grad_(), u.clone().requires_grad_()
+    (dyn(xr, ur) * w).sum().backward()
+    e = 1e-6
+    for j in range(dyn.n_state):
+        d = torch.zeros_like(x); d[:, j] = e
+        fd = ((dyn(x + d, u) - dyn(x - d, u)) * w).sum(1) / (2 * e)
+        np.testing.assert_allclose(xr.grad[:, j].cpu().numpy(), fd.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    fd = ((dyn(x, u + e) - dyn(x, u - e)) * w).sum(1) / (2 * e)
+    np.testing.assert_allclose(ur.grad[:, 0].cpu().numpy(), fd.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_bad_arguments(dynmod):
+    import ctypes
+    from diff_qp_mpc_amd import _lib
+    lib = _lib.load()
+    assert lib.dqp_dyn_sizes(99, None, None) == -1
+    assert lib.dqp_dyn_step(99, 4, None, None, 0.05, None, None) == -1
+    assert lib.dqp_dyn_step(2, 4, None, None, 0.05, None, None) == -1       # null pointers
+    assert lib.dqp_dyn_step(2, 0, None, None, 0.05, None, None) == 0        # empty batch
+    assert lib.dqp_dyn_forward_dynamics(5, 4, *([None] * 7)) == -1          # not a robot
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dynmod.DeviceDynamics("cartpole1l")(torch.zeros(2, 4, dtype=torch.float64), torch.zeros(2, 1, dtype=torch.float64))
+    with pytest.raises(ValueError):
+        dynmod.DeviceDynamics("acrobot")

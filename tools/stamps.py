@@ -14,7 +14,7 @@ if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(_build.SO):
     for obj, cmd in _build._jobs():
         # only the metric-size forward kernels and the host file carry stamps; every other object
         # is the product's own
-        if os.path.basename(obj) in ("dqp_r16n_30_30_15.o", "dqp_r16f_30_30_15.o", "dqp_pdipm.o"):
+        if os.path.basename(obj) in ("dqp_r16n_30_30_15.o", "dqp_r16f_30_30_15.o", "dqp_pdipm.o", "dqp_al.o"):
             o2 = obj.replace(".o", ".stamps.o")
             procs.append(subprocess.Popen([c if c != obj else o2 for c in cmd] + ["-DDQP_STAMPS"]))
             objs.append(o2)
