@@ -138,8 +138,10 @@ def compute_cost_gradient(xu, Q, q, diag_cost=True):
 def merit_function(xu, Q, q, dx, x0, lamda, rho, x_lower, x_upper, u_lower, u_upper, diag_cost=True):
     """cost + rho/2 |res_clamp|^2 + lamda . res; a leading candidate axis (n_ls,B,T,nt) is
     folded into the batch (al_utils.py:37-59)."""
+    m_ctrl = xu.shape[-1] - x0.shape[-1]
     if (xu.is_cuda and not torch.is_grad_enabled() and torch.is_tensor(u_lower) and u_lower.dim() == 1
-            and x_lower is None and x_upper is None):
+            and torch.is_tensor(u_upper) and u_lower.numel() == m_ctrl and u_upper.numel() == m_ctrl
+            and x_lower is None and x_upper is None):   # the kernel reads n_ctrl bounds per knot
         return _merit_fused(xu, Q, q, dx, x0, lamda, rho, u_lower, u_upper)
     if xu.dim() == 4:
         k, B = xu.shape[:2]

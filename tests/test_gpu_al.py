@@ -102,34 +102,78 @@ def test_newton_step_reports_indefinite_hessian():
     assert np.isnan(u[1]).all() and np.allclose(u[0], -1.0) and np.allclose(u[2], -1.0)
 
 
-@pytest.mark.parametrize("B,T", [(5, 4), (33, 20), (1, 2)])
-def test_assemble_jacobian_kernel(B, T):
-    """dqp_al_assemble vs the index-scatter construction of al_utils.py:162-318 (restated in torch
-    in al_utils.constraint_jacobian and in numpy in oracle/al_oracle.py) and the two bmm's of
-    merit_grad_hessian: exact for Jc (copies and +-1), 1e-12 for the products."""
+class LinearJac(torch.nn.Module):
+    """x+ = A x + B u with m controls: exercises the [upper(m), lower(m)] row interleave for m > 1."""
+
+    def __init__(self, n, m, seed):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.A = (torch.eye(n, dtype=torch.float64) + 0.1 * torch.randn(n, n, generator=g, dtype=torch.float64)).cuda()
+        self.B = torch.randn(n, m, generator=g, dtype=torch.float64).cuda()
+
+    def step_np(self, x, u):
+        A, Bm = self.A.cpu().numpy(), self.B.cpu().numpy()
+        N = x.shape[0]
+        return x @ A.T + u @ Bm.T, np.broadcast_to(A, (N,) + A.shape).copy(), np.broadcast_to(Bm, (N,) + Bm.shape).copy()
+
+    def forward(self, x, u):
+        xn = x @ self.A.T + u @ self.B.T
+        N = x.shape[0]
+        return xn, (self.A.expand(N, -1, -1), self.B.expand(N, -1, -1))
+
+
+@pytest.mark.parametrize("B,T,n,m", [(5, 4, 2, 1), (33, 20, 2, 1), (1, 2, 2, 1), (7, 6, 3, 2), (4, 5, 4, 3)])
+def test_assemble_jacobian_kernel(B, T, n, m):
+    """dqp_al_assemble against the numpy oracle (oracle/al_oracle.py, pinned to the reference's
+    ns_J / ns_Jc / ns_res by test_oracle_golden.py): exact for Jc (copies and +-1), 1e-12 for the
+    products J^T lam + rho Jc^T res_c.  m > 1 exercises the [upper(m), lower(m)] row interleave."""
     from diff_qp_mpc_amd import al_utils
-    gen = torch.Generator().manual_seed(T)
-    n, m = 2, 1
+    gen = torch.Generator().manual_seed(T + 10 * m)
     xu = torch.randn(B, T, n + m, generator=gen, dtype=torch.float64).cuda()
     x0 = torch.randn(B, n, generator=gen, dtype=torch.float64).cuda()
     lam = torch.randn(B, T * n + 2 * T * m, generator=gen, dtype=torch.float64).cuda()
     rho = (10.0 ** torch.randint(0, 3, (B, 1), generator=gen).double()).cuda()
     lo, hi = torch.full((m,), -0.5, dtype=torch.float64).cuda(), torch.full((m,), 0.5, dtype=torch.float64).cuda()
-    res, resc, J, Jc_ref = al_utils.constraint_jacobian(xu, x0, PendulumJac(), lo, hi)
-    g_ref = torch.bmm(lam[:, None], J)[:, 0] + rho * torch.bmm(resc[:, None], Jc_ref)[:, 0]
-    Jc, gterm = al_utils.assemble_jacobian(xu, x0, PendulumJac(), lam, rho, lo, hi)
-    assert torch.equal(Jc, Jc_ref)
-    np.testing.assert_allclose(gterm.cpu().numpy(), g_ref.cpu().numpy(), rtol=1e-12, atol=1e-12)
+    if m == 1:
+        jac, step = PendulumJac(), al_oracle.pendulum_step
+    else:
+        jac = LinearJac(n, m, 3)
+        step = jac.step_np
+    res, resc, J, Jc_ref = al_oracle.constraint_jacobian(xu.cpu().numpy(), x0.cpu().numpy(), lo.cpu().numpy(),
+                                                         hi.cpu().numpy(), step=step)
+    g_ref = np.einsum("bc,bcn->bn", lam.cpu().numpy(), J) + rho.cpu().numpy() * np.einsum("bc,bcn->bn", resc, Jc_ref)
+    Jc, gterm = al_utils.assemble_jacobian(xu, x0, jac, lam, rho, lo, hi)
+    np.testing.assert_allclose(Jc.cpu().numpy(), Jc_ref, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(gterm.cpu().numpy(), g_ref, rtol=1e-12, atol=1e-12)
     assert int((resc[:, T * n:] > 0).sum()) > 0 or B == 1            # some inequalities active
+    # and the package's own torch construction (the non-fused path) agrees with the oracle too
+    _, _, J_t, Jc_t = al_utils.constraint_jacobian(xu, x0, jac, lo, hi)
+    np.testing.assert_allclose(J_t.cpu().numpy(), J, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(Jc_t.cpu().numpy(), Jc_ref, rtol=0, atol=1e-15)
 
 
-@pytest.mark.parametrize("B,T,k", [(5, 4, 1), (33, 20, 20), (2, 35, 3)])
-def test_merit_kernel(B, T, k):
-    """dqp_al_merit vs the torch restatement of al_utils.merit_function (al_utils.py:37-59), with
-    and without a leading candidate axis (the 20-way line search)."""
+@pytest.mark.parametrize("name", AL_CASES)
+def test_assemble_jacobian_kernel_vs_reference_golden(name):
+    """The reference's own constraint Jacobian at the first iterate (ns_xu -> ns_Jc; al_utils.py:162-318)
+    and its merit gradient (ns_grad, al_utils.py:62-102)."""
+    from diff_qp_mpc_amd import al_utils
+    g = load(name)
+    xu, x0 = dev(g["ns_xu"]), dev(g["in_x0"])
+    B = xu.shape[0]
+    lam = torch.zeros(B, g["ns_Jc"].shape[1], dtype=torch.float64, device="cuda")
+    rho = dev(g["ns_rho"])
+    Jc, gterm = al_utils.assemble_jacobian(xu, x0, PendulumJac(), lam, rho, dev(g["in_u_lower"]), dev(g["in_u_upper"]))
+    np.testing.assert_allclose(Jc.cpu().numpy(), g["ns_Jc"], rtol=0, atol=1e-13)
+    grad = (dev(g["ns_Qd"]) * xu + dev(g["in_c"])).reshape(B, -1) + gterm
+    np.testing.assert_allclose(grad.cpu().numpy(), g["ns_grad"], rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("B,T,k,n,m", [(5, 4, 1, 2, 1), (33, 20, 20, 2, 1), (2, 35, 3, 2, 1), (6, 5, 20, 3, 2)])
+def test_merit_kernel(B, T, k, n, m):
+    """dqp_al_merit against a numpy restatement of al_utils.merit_function (al_utils.py:37-59) built
+    on the oracle's residuals, with and without a leading candidate axis (the 20-way line search)."""
     from diff_qp_mpc_amd import al_utils
     gen = torch.Generator().manual_seed(T + k)
-    n, m = 2, 1
     shape = (k, B, T, n + m) if k > 1 else (B, T, n + m)
     xu = torch.randn(*shape, generator=gen, dtype=torch.float64).cuda()
     x0 = torch.randn(B, n, generator=gen, dtype=torch.float64).cuda()
@@ -138,11 +182,25 @@ def test_merit_kernel(B, T, k):
     lam = torch.randn(B, T * n + 2 * T * m, generator=gen, dtype=torch.float64).cuda()
     rho = (10.0 ** torch.randint(0, 3, (B, 1), generator=gen).double()).cuda()
     lo, hi = torch.full((m,), -0.5, dtype=torch.float64).cuda(), torch.full((m,), 0.5, dtype=torch.float64).cuda()
+    if m == 1:
+        dyn, step = Pendulum(), al_oracle.pendulum_step
+    else:
+        lj = LinearJac(n, m, 3)
+        dyn, step = (lambda x, u: lj(x, u)[0]), lj.step_np
     with torch.no_grad():
-        got = al_utils.merit_function(xu, Q, q, Pendulum(), x0, lam, rho, None, None, lo, hi)
-    with torch.enable_grad():          # grad mode on -> the torch path
-        want = al_utils.merit_function(xu, Q, q, Pendulum(), x0, lam, rho, None, None, lo, hi)
-    np.testing.assert_allclose(got.cpu().numpy(), want.detach().cpu().numpy(), rtol=1e-12, atol=1e-10)
+        got = al_utils.merit_function(xu, Q, q, dyn, x0, lam, rho, None, None, lo, hi)
+    xs = xu.cpu().numpy().reshape(-1, B, T, n + m)
+    want = []
+    for cand in xs:
+        res, resc, _, _ = al_oracle.constraint_jacobian(cand, x0.cpu().numpy(), lo.cpu().numpy(), hi.cpu().numpy(), step=step)
+        cost = (0.5 * cand * Q.cpu().numpy() * cand + q.cpu().numpy() * cand).sum((1, 2))
+        want.append(cost + 0.5 * rho.cpu().numpy()[:, 0] * (resc * resc).sum(1) + (lam.cpu().numpy() * res).sum(1))
+    np.testing.assert_allclose(got.cpu().numpy().reshape(-1, B), np.stack(want), rtol=1e-12, atol=1e-10)
+    # a length-1 bound with m > 1 must not take the fused path (it would read past the bound array)
+    if m > 1:
+        with torch.no_grad():
+            alt = al_utils.merit_function(xu, Q, q, dyn, x0, lam, rho, None, None, lo[:1], hi[:1])
+        np.testing.assert_allclose(alt.cpu().numpy().reshape(-1, B), np.stack(want), rtol=1e-12, atol=1e-10)
 
 
 @pytest.mark.parametrize("name", AL_CASES)
@@ -176,3 +234,78 @@ def test_al_mpc_two_calls_vs_reference(name):
     np.testing.assert_allclose(u2.cpu().numpy(), g["u2"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(ctrl.lamda_prev.cpu().numpy(), g["lam2"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(ctrl.rho_prev.cpu().numpy(), g["rho2"], rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("name,robot", [("CFG3_cartpole1l_T20_b4", "cartpole1l"), ("CFG5_cartpole2l_T5_b4", "cartpole2l")])
+def test_al_mpc_cartpole_vs_reference(name, robot):
+    """BASELINE config 3 (cartpole-1, n 4, m 1, T 20) and the config-5 robot (cartpole-2, n 6, T 5)
+    through AL_mpc.MPC with the DEVICE dynamics registry, against the reference's AL_mpc.MPC run on
+    its own CasADi-generated dynamics (make_golden_cfg3.py): cold call with gradients, then the
+    warm-started call.  x, u are float32 in the reference (AL_mpc.py:319-320): rtol 1e-4 / atol 1e-4
+    (states reach +-pi, controls +-100); multipliers rtol 1e-5 / atol 1e-5; rho exact."""
+    from diff_qp_mpc_amd import AL_mpc, al_utils
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    g = load(name)
+    B, T = g["in_Qd"].shape[:2]
+    dyn = DeviceDynamics(robot, dt=float(g["dt"]))
+    nx, nu = dyn.n_state, dyn.n_ctrl
+    x0 = dev(g["in_x0"])
+    C = torch.diag_embed(dev(g["in_Qd"])).requires_grad_()
+    c = dev(g["in_c"], grad=True)
+    ctrl = AL_mpc.MPC(nx, nu, T, u_lower=dev(g["in_u_lower"]), u_upper=dev(g["in_u_upper"]), n_batch=B,
+                      verbose=0, solver_type="dense", dtype=torch.float64, eps=1e-5,
+                      exit_unconverged=False, backprop=False)
+    ctrl.reinitialize(x0, torch.ones(B, T, 1, device="cuda"))
+    ctrl.x_init, ctrl.u_init = dev(g["in_x_init"]), dev(g["in_u_init"])
+    x, u = ctrl(x0, al_utils.QuadCost(C, c), dyn, dyn.jac)
+    np.testing.assert_allclose(x.detach().cpu().numpy(), g["x1"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(u.detach().cpu().numpy(), g["u1"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ctrl.lamda_prev.cpu().numpy(), g["lam1"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ctrl.rho_prev.cpu().numpy(), g["rho1"], rtol=0, atol=0)
+    (x.double().sum() + 2.0 * u.double().sum()).backward()
+    np.testing.assert_allclose(C.grad.diagonal(dim1=-2, dim2=-1).cpu().numpy(), g["dC1"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(c.grad.cpu().numpy(), g["dc1"], rtol=1e-4, atol=1e-5)
+    x2, u2 = ctrl(x0, al_utils.QuadCost(C.detach(), c.detach()), dyn, dyn.jac)
+    np.testing.assert_allclose(x2.cpu().numpy(), g["x2"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(u2.cpu().numpy(), g["u2"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ctrl.lamda_prev.cpu().numpy(), g["lam2"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ctrl.rho_prev.cpu().numpy(), g["rho2"], rtol=0, atol=0)
+
+
+def test_config3_full_size_properties():
+    """B = 4096, n 4, m 1, T = 20 (BASELINE config 3 size): one AL_mpc.MPC call on the device
+    cartpole.  Size-independent properties: x_0 pinned to x0 (al_utils.py:515), finite outputs,
+    multipliers of the inequality block non-negative (AL_mpc.py:300-301), rho = 100 after two outer
+    iterations of a cold start (AL_mpc.py:307), and batch-size independence against the reference:
+    the first four problems are the golden fixture's."""
+    from diff_qp_mpc_amd import AL_mpc, al_utils
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    B, T = 4096, 20
+    dyn = DeviceDynamics("cartpole1l", dt=0.05)
+    nx, nu = 4, 1
+    rng = np.random.default_rng(0)
+    x0 = dev(rng.uniform(-np.pi, np.pi, (B, nx)))
+    Qd = torch.cat([torch.ones(nx), 1e-8 * torch.ones(nu)]).double().cuda().repeat(B, T, 1)
+    ramp = torch.linspace(1.0, 0.0, T, dtype=torch.float64, device="cuda")[None, :, None]
+    x_ref = x0[:, None, :] * ramp
+    xu_ref = torch.cat([x_ref, torch.zeros(B, T, nu, dtype=torch.float64, device="cuda")], -1)
+    C = torch.diag_embed(Qd)
+    c = -(Qd * xu_ref)
+    lo, hi = dev([-100.0]), dev([100.0])
+    ctrl = AL_mpc.MPC(nx, nu, T, u_lower=lo, u_upper=hi, n_batch=B, verbose=0, solver_type="dense",
+                      dtype=torch.float64, eps=1e-5, exit_unconverged=False, backprop=False)
+    ctrl.reinitialize(x0, torch.ones(B, T, 1, device="cuda"))
+    ctrl.x_init, ctrl.u_init = x_ref.clone(), torch.zeros(B, T, nu, dtype=torch.float64, device="cuda")
+    x, u = ctrl(x0, al_utils.QuadCost(C, c), dyn, dyn.jac)
+    assert x.shape == (B, T, nx) and u.shape == (B, T, nu)
+    assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(u).all())
+    assert float((x[:, 0].double() - x0).abs().max()) < 1e-6           # float32 output of an exact pin
+    assert float(ctrl.lamda_prev[:, T * nx:].min()) >= 0.0
+    assert set(ctrl.rho_prev.unique().tolist()) <= {100.0}
+    # samples are independent: the first four problems are the golden's (same generator stream), so
+    # inside the 4096-batch they must come out as the reference computed them in a batch of four
+    g = load("CFG3_cartpole1l_T20_b4")
+    np.testing.assert_allclose(x0[:4].cpu().numpy(), g["in_x0"], rtol=0, atol=0)
+    np.testing.assert_allclose(x[:4].cpu().numpy(), g["x1"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(u[:4].cpu().numpy(), g["u1"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ctrl.lamda_prev[:4].cpu().numpy(), g["lam1"], rtol=1e-5, atol=1e-5)
