@@ -137,14 +137,16 @@ __device__ __forceinline__ double trimatvec(const double *L, int ld, int n, doub
 }
 
 // In-place lower Cholesky of the n x n matrix in LDS; rd = 1/L[i][i] on lane i.
-__device__ __forceinline__ bool chol_factor(double *L, int ld, int n, int lane, double &rd)
+__device__ __forceinline__ bool chol_factor(double *L, int ld, int n, int lane, double &rd, double reltol = 0.0)
 {
     bool ok = true;
     rd = 0.0;
+    double pmax = 0.0;      // reltol > 0: a pivot collapsed below reltol x the largest one = singular
     for (int k = 0; k < n; ++k) {
         WSYNC();
         double dk = L[k * ld + k];
-        if (!(dk > 0.0)) { ok = false; dk = 1.0; }
+        if (!(dk > reltol * pmax)) { ok = false; dk = 1.0; }
+        pmax = fmax(pmax, dk);
         const double sq = sqrt(dk), r = 1.0 / sq;
         const bool act = lane > k && lane < n;
         double c = 0.0;
@@ -332,7 +334,7 @@ __device__ __forceinline__ int qp_setup(const KParams &P, const Lds &S, int qp, 
                 S.L1[i * lde + j] = a;
             }
         }
-        if (!chol_factor(S.L1, lde, E, lane, rd1) && status == DQP_STATUS_OK)
+        if (!chol_factor(S.L1, lde, E, lane, rd1, 1e-13) && status == DQP_STATUS_OK)
             status = DQP_STATUS_A_RANK_DEF;
         // At = L1^-1 Ah  (lanes = columns)
         if (lane < N) {

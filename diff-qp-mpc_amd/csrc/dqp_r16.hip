@@ -118,7 +118,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
                     for (int s = 0; s < SE; ++s) L1[s][j] = fma(st.Ah[s][c], ab, L1[s][j]);
                 }
             }
-            if (!chol_rows<SE, EC>(L1, st.rd1, r) && st.status == DQP_STATUS_OK)
+            if (!chol_rows<SE, EC>(L1, st.rd1, r, 1e-13) && st.status == DQP_STATUS_OK)
                 st.status = DQP_STATUS_A_RANK_DEF;
             // eliminate with unscaled rows, scale once at the end
 #pragma unroll

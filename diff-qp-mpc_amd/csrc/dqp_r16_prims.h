@@ -194,18 +194,22 @@ __device__ __forceinline__ void mv_tr(const double (&Mx)[SR][NC], const double (
 
 // ------------------------------------------------------------------ factorizations in registers
 // Lower Cholesky of the row-distributed SPD matrix (in place; strict upper part zeroed).
-// rd[s] = 1/L[i][i] for the lane's rows.  Returns false on a non-positive pivot.
+// rd[s] = 1/L[i][i] for the lane's rows.  Returns false on a pivot that is not positive, or --
+// with reltol > 0 -- that has collapsed below reltol x the largest pivot seen (a numerically
+// singular matrix: duplicated / dependent equality rows give a round-off-sized positive pivot).
 template <int S, int N>
-__device__ __forceinline__ bool chol_rows(double (&L)[S][N], double (&rd)[S], int r)
+__device__ __forceinline__ bool chol_rows(double (&L)[S][N], double (&rd)[S], int r, double reltol = 0.0)
 {
     bool ok = true;
+    double pmax = 0.0;
 #pragma unroll
     for (int s = 0; s < S; ++s) rd[s] = 0.0;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const int sk = k >> 4, lk = k & 15;
         double dk = rb(L[sk][k], lk);
-        if (!(dk > 0.0)) { ok = false; dk = 1.0; }
+        if (!(dk > reltol * pmax)) { ok = false; dk = 1.0; }
+        pmax = fmax(pmax, dk);
         const double ri = frsqrt(dk);
         if (r == lk) rd[sk] = ri;
         PIN(rd[sk]);

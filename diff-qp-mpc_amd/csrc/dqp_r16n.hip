@@ -285,6 +285,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
 
     if (E > 0) {
         // C: reverse Householder LQ of Ah; reflectors applied to the rows of Ah (above k) and Gh
+        double nmax = 0.0;
 #pragma unroll
         for (int k = E - 1; k >= 0; --k) {
             const int sk = k >> 4, lk = k & 15, ck = R + k;
@@ -298,7 +299,9 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
                 u[c] = rb(st.Ah[sk][c], lk);
                 nrm2 = fma(u[c], u[c], nrm2);
             }
-            if (!(nrm2 > 0.0)) { if (st.status == DQP_STATUS_OK) st.status = DQP_STATUS_A_RANK_DEF; nrm2 = 1.0; }
+            // |U[k][k]|^2 = nrm2: a row that (numerically) lies in the span of the rows below it
+            if (!(nrm2 > 1e-26 * nmax)) { if (st.status == DQP_STATUS_OK) st.status = DQP_STATUS_A_RANK_DEF; nrm2 = 1.0; }
+            nmax = fmax(nmax, nrm2);
             const double vk = u[ck];
             const double alpha = -copysign(sqrt(nrm2), vk);
             const double uck = vk - alpha;
