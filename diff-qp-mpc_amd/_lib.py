@@ -34,6 +34,7 @@ DQP_FLAG_GENERIC_ONLY = 2
 DQP_FLAG_NO_NULLSPACE = 4
 DQP_FLAG_BACKWARD_CTX = 8
 DQP_FLAG_BATCH_TERMINATION = 16
+DQP_FLAG_HISTORY_ONLY = 32
 DQP_STATUS_Q_NOT_PD = 1
 DQP_STATUS_A_RANK_DEF = 2
 DQP_MAX_DIM = 64

@@ -170,10 +170,13 @@ def _merit_fused(xu, Q, q, dx, x0, lamda, rho, u_lower, u_upper):
     xu64, xn64 = d64(flat), d64(x_next)
     merit = torch.empty(k * B, dtype=torch.float64, device=xu.device)
     dims = _lib.dqp_al_mpc_dims(B, n, m, T)
+    # the converted inputs must outlive the launch: a temporary freed right after data_ptr() is
+    # handed back to the caching allocator and overwritten by the NEXT conversion before the
+    # kernel (enqueued after all of them) reads it
+    keep = [d64(x0), d64(Q), d64(q), d64(lamda), d64(rho).reshape(B), d64(u_lower), d64(u_upper)]
     with torch.cuda.device(xu.device):
-        rc = lib.dqp_al_merit(ctypes.byref(dims), k, _ptr(xu64), _ptr(xn64), _ptr(d64(x0)), _ptr(d64(Q)),
-                              _ptr(d64(q)), _ptr(d64(lamda)), _ptr(d64(rho).reshape(B)), _ptr(d64(u_lower)),
-                              _ptr(d64(u_upper)), _ptr(merit), _stream(xu.device))
+        rc = lib.dqp_al_merit(ctypes.byref(dims), k, _ptr(xu64), _ptr(xn64), *[_ptr(t) for t in keep],
+                              _ptr(merit), _stream(xu.device))
     _lib.check(rc, "dqp_al_merit")
     return merit.to(xu.dtype)
 

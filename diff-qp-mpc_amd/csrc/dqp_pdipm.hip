@@ -803,6 +803,7 @@ dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, cons
     P.eps = opts ? opts->eps : 1e-12;            // the batch rule uses the reference's eps itself
     term_bind_pass1(P, termination);
     if ((rc = forward_once(P, lds, workspace, stream)) != DQP_OK) return rc;
+    if (P.flags & DQP_FLAG_HISTORY_ONLY) return DQP_OK;
     if ((rc = term_decide(P, termination, stream)) != DQP_OK) return rc;
     term_bind_pass2(P, termination);
     return forward_once(P, lds, workspace, stream);

@@ -1,0 +1,232 @@
+"""DEQ-MPC call pattern: the solver-facing part of deqmpc/policies.py, on the
+fused kernels.
+
+    DEQLayer       policies.py:191-430   the MLP variant (layer_type "mlp"; state-dict keys as the
+                                         reference's, so its checkpoints load)
+    Tracking_MPC   policies.py:567-686   p = -(Q x_ref); AL_mpc.MPC ("al", the reference's default,
+                                         deqmpc/train.py:61) or qp_wrapper.MPC ("ip")
+    DEQMPCPolicy   policies.py:432-529   deq_iter x [DEQLayer -> Tracking_MPC]; every iterate is returned
+    compute_loss_deqmpc / add_loss_based_on_out_type   policies.py:800-833
+    train_step     the body of deqmpc/train.py:135-175 for one batch, plus what the reference does not
+                   have: data-parallel training -- each rank solves its own shard of trajectories
+                   (the solves never communicate) and the DEQLayer gradients are summed over ranks with
+                   ONE flat all_reduce (RCCL) before the optimiser step.
+
+The dynamics are passed as in the reference (`env.dynamics`, `env.dynamics_derivatives`); a
+dynamics.DeviceDynamics (its `.jac` is the derivatives callable) keeps every solver call on the GPU.
+"""
+import torch
+import torch.nn as nn
+
+from . import AL_mpc as al_mpc
+from . import al_utils
+from . import qp_wrapper as ip_mpc
+
+
+class DEQLayer(nn.Module):
+    """One DEQ iteration of the reference's trajectory network, MLP flavour (policies.py:191-430,
+    layer_type "mlp", deq_out_type 1 or 2): input = current reference trajectory, hidden state z."""
+
+    def __init__(self, args, env):
+        super().__init__()
+        self.args = args
+        self.nu, self.nx, self.nq = env.nu, env.nx, args.nq
+        self.dt, self.T, self.hdim = env.dt, args.T, args.hdim
+        self.layer_type = getattr(args, "layer_type", "mlp")
+        self.out_type = args.deq_out_type
+        if self.layer_type != "mlp":
+            raise NotImplementedError("only the MLP DEQLayer is mirrored (the solver call pattern is the same)")
+        if self.out_type not in (1, 2):
+            raise NotImplementedError("deq_out_type 1 / 2 (state prediction), as DEQMPCPolicy.forward handles")
+        self.in_dim = self.nx + self.nx * (self.T - 1)                             # policies.py:313-315
+        self.inp_layer = nn.Sequential(nn.Linear(self.in_dim, self.hdim), nn.LayerNorm(self.hdim))
+        self.fcdeq1, self.lndeq1, self.reludeq1 = nn.Linear(self.hdim, self.hdim), nn.LayerNorm(self.hdim), nn.ReLU()
+        self.fcdeq2, self.lndeq2, self.reludeq2 = nn.Linear(self.hdim, self.hdim), nn.LayerNorm(self.hdim), nn.ReLU()
+        self.lndeq3 = nn.LayerNorm(self.hdim)
+        self.out_dim = self.nx * (self.T - 1) if self.out_type == 1 else self.nx * self.T
+        self.out_layer = nn.Sequential(nn.Linear(self.hdim, self.out_dim))
+
+    def init_z(self, bsz):
+        p = self.fcdeq1.weight
+        return torch.zeros(bsz, self.hdim, dtype=torch.float32, device=p.device)
+
+    def deq_layer(self, x, z):                                                    # policies.py:277-283
+        z = self.lndeq1(self.reludeq1(self.fcdeq1(z)))
+        return self.lndeq3(self.reludeq2(z + self.lndeq2(x + self.fcdeq2(z))))
+
+    def forward(self, x, z):
+        z_out = self.deq_layer(self.inp_layer(x), z)
+        steps = self.T - 1 if self.out_type == 1 else self.T
+        dx_ref = self.out_layer(z_out).view(-1, steps, self.nx)
+        vel_ref = dx_ref[..., self.nq:]
+        pos_ref = dx_ref[..., :self.nq] * self.dt + x[:, None, :self.nq]           # policies.py:221-223
+        return torch.cat([pos_ref, vel_ref], dim=-1), z_out
+
+
+class Tracking_MPC(nn.Module):
+    """Tracks the network's reference with the differentiable MPC (policies.py:567-686)."""
+
+    def __init__(self, args, env):
+        super().__init__()
+        self.args = args
+        self.nu, self.nx, self.nq, self.dt, self.T = env.nu, env.nx, getattr(env, "nq", args.nq), env.dt, args.T
+        self.dyn, self.dyn_jac = env.dynamics, env.dynamics_derivatives
+        self.device = args.device
+        self.dtype = torch.float64 if args.dtype == "double" else torch.float32
+        self.u_upper = torch.as_tensor(env.action_space.high).to(self.device)
+        self.u_lower = torch.as_tensor(env.action_space.low).to(self.device)
+        self.qp_iter, self.eps, self.warm_start, self.bsz = args.qp_iter, args.eps, args.warm_start, args.bsz
+        if args.Q is None:
+            Q = torch.ones(self.nx, dtype=self.dtype, device=self.device)
+            R = torch.ones(self.nu, dtype=self.dtype, device=self.device)
+        else:
+            Q, R = args.Q.to(self.device), args.R.to(self.device)
+        Qd = torch.cat([Q, R], dim=0).to(self.dtype)
+        self.Q = torch.diag(Qd).repeat(self.bsz, self.T, 1, 1)
+        self.u_init = torch.randn(self.bsz, self.T, self.nu, dtype=self.dtype, device=self.device)
+        self.x_init = None
+        self.single_qp_solve = self.qp_iter == 1
+        if args.solver_type == "al":
+            self.ctrl = al_mpc.MPC(self.nx, self.nu, self.T, u_lower=self.u_lower, u_upper=self.u_upper,
+                                   exit_unconverged=False, eps=1e-5, n_batch=self.bsz, backprop=False, verbose=0,
+                                   u_init=self.u_init, solver_type="dense", dtype=self.dtype)
+        else:
+            self.ctrl = ip_mpc.MPC(self.nx, self.nu, self.T, u_lower=self.u_lower.double(), u_upper=self.u_upper.double(),
+                                   qp_iter=self.qp_iter, exit_unconverged=False, eps=1e-5, n_batch=self.bsz,
+                                   backprop=False, verbose=0, u_init=self.u_init.transpose(0, 1),
+                                   grad_method=ip_mpc.GradMethods.ANALYTIC, solver_type="dense",
+                                   single_qp_solve=self.single_qp_solve)
+
+    def compute_p(self, x_ref):
+        self.p = -(self.Q * x_ref.unsqueeze(-2)).sum(dim=-1)                      # policies.py:669-680
+        return self.p
+
+    def forward(self, x0, xu_ref, x_ref, u_ref):
+        al = self.args.solver_type == "al"
+        if al:
+            xu_ref = torch.cat([x_ref, u_ref], dim=-1)
+            if self.x_init is None:
+                self.x_init = self.ctrl.x_init = x_ref
+                self.u_init = self.ctrl.u_init = u_ref
+        self.compute_p(xu_ref)
+        if al:
+            cost = al_utils.QuadCost(self.Q, self.p)
+            xs, us = self.ctrl(x0, cost, self.dyn, self.dyn_jac)
+        else:
+            cost = ip_mpc.QuadCost(self.Q.transpose(0, 1), self.p.transpose(0, 1))
+            self.ctrl.u_init = self.u_init.transpose(0, 1)
+            xs, us = self.ctrl(x0.to(self.dtype), cost, self.dyn, self.dyn_jac)
+            xs, us = xs.transpose(0, 1).to(x0.dtype), us.transpose(0, 1).to(x0.dtype)     # the network's dtype
+        self.u_init = us.clone().detach()
+        return xs, us
+
+    def reinitialize(self, x, mask):
+        self.u_init = torch.randn(self.bsz, self.T, self.nu, dtype=x.dtype, device=x.device)
+        self.x_init = None
+        self.ctrl.reinitialize(x, mask)
+
+
+class DEQMPCPolicy(nn.Module):
+    """deq_iter rounds of [network proposes a reference -> MPC tracks it -> the solution feeds the
+    network again] (policies.py:432-529).  Returns every round's (network reference, MPC states,
+    MPC actions): the imitation loss supervises all of them."""
+
+    def __init__(self, args, env):
+        super().__init__()
+        self.args = args
+        self.nu, self.nx, self.nq, self.T, self.dt = env.nu, env.nx, args.nq, args.T, env.dt
+        self.device, self.deq_iter = args.device, args.deq_iter
+        self.model = DEQLayer(args, env).to(self.device)
+        self.out_type = args.policy_out_type
+        self.tracking_mpc = Tracking_MPC(args, env)
+
+    def forward(self, x, x_gt, u_gt, mask, iter=0, qp_solve=True, lastqp_solve=False):
+        bsz = x.shape[0]
+        x_ref = torch.cat([x] * self.T, dim=-1).detach().clone()
+        nominal_actions = torch.zeros((bsz, self.T, self.nu), device=self.device)
+        z = self.model.init_z(bsz)
+        trajs = []
+        if self.args.solver_type == "al":
+            self.tracking_mpc.reinitialize(x, mask[:, :, None])
+        for _ in range(self.deq_iter):
+            x_ref, z = self.model(x_ref, z)
+            if self.model.out_type == 1:                      # the current state is known: prepend it
+                x_ref = torch.cat([x[:, None, :], x_ref.view(-1, self.T - 1, self.nx)], dim=1)
+            else:
+                x_ref = x_ref.view(-1, self.T, self.nx)
+            xu_ref = torch.cat([x_ref, nominal_actions], dim=-1)
+            x_ref_tr, u_ref_tr = x_ref, nominal_actions
+            nominal_states = x_ref
+            if qp_solve:
+                nominal_states, nominal_actions = self.tracking_mpc(x, xu_ref, x_ref_tr, u_ref_tr)
+            trajs.append((x_ref, nominal_states, nominal_actions))
+            x_ref = nominal_states.reshape(bsz, -1).detach().clone()              # the solution feeds the DEQ again
+        with torch.no_grad():
+            nxt = self.tracking_mpc.dyn(x_ref.view(-1, self.nx).double(), u_gt.reshape(-1, self.nu).double())
+            dyn_res = nxt.reshape(bsz, -1).norm(dim=1).mean()
+        if lastqp_solve:                                      # policies.py:524-527
+            ns, na = self.tracking_mpc(x, xu_ref, x_ref_tr, u_ref_tr)
+            trajs[-1] = (trajs[-1][0], ns, na)
+        return trajs, dyn_res
+
+
+def add_loss_based_on_out_type(policy, out_type, gt_states, gt_actions, gt_mask, nominal_states, nominal_actions):
+    """policies.py:818-833: masked L1 on actions (0, 2), states (1, 2) or configurations (3)."""
+    loss = 0.0
+    m = gt_mask[:, :, None]
+    if out_type in (0, 2):
+        loss = loss + torch.abs((nominal_actions - gt_actions) * m).sum(dim=-1).mean()
+    if out_type in (1, 2):
+        loss = loss + torch.abs((nominal_states - gt_states) * m).sum(dim=-1).mean()
+    if out_type == 3:
+        loss = loss + torch.abs((nominal_states[..., :policy.nq] - gt_states[..., :policy.nq]) * m).sum(dim=-1).mean()
+    return loss
+
+
+def compute_loss_deqmpc(policy, gt_states, gt_actions, gt_mask, trajs):
+    """policies.py:800-808: every DEQ-MPC round is supervised; loss_end is the last round's term."""
+    loss = 0.0
+    for (_, ns, na) in trajs:
+        loss = loss + add_loss_based_on_out_type(policy, policy.out_type, gt_states, gt_actions, gt_mask, ns, na)
+    _, ns, na = trajs[-1]
+    return loss, add_loss_based_on_out_type(policy, policy.out_type, gt_states, gt_actions, gt_mask, ns, na)
+
+
+def allreduce_gradients(module, group=None, world_size=None):
+    """Sum the gradients of `module` over the ranks of `group` with ONE flat all_reduce (the DEQLayer
+    has ~0.1-1 MB of parameters: a single latency-bound collective over xGMI beats per-tensor calls),
+    then divide by the world size: every rank's loss is a mean over ITS shard, so the average of the
+    rank gradients is the gradient of the mean over the global batch for equal shards."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0
+    ws = world_size or dist.get_world_size(group)
+    if ws == 1:
+        return 0
+    ps = [p for p in module.parameters() if p.requires_grad]
+    for p in ps:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(ws)
+    off = 0
+    for p in ps:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+    return flat.numel()
+
+
+def train_step(policy, optimizer, x0, gt_states, gt_actions, gt_mask, group=None, qp_solve=True,
+               lastqp_solve=False):
+    """One imitation-learning step on this rank's shard (deqmpc/train.py:150-175): forward through
+    deq_iter solver calls, L1 loss on every iterate, backward through the solvers' implicit
+    derivatives, gradient all-reduce, optimiser step.  Returns (loss, loss_end, dyn_res) tensors."""
+    trajs, dyn_res = policy(x0, gt_states, gt_actions, gt_mask, qp_solve=qp_solve, lastqp_solve=lastqp_solve)
+    loss, loss_end = compute_loss_deqmpc(policy, gt_states, gt_actions, gt_mask, trajs)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    allreduce_gradients(policy.model, group)
+    optimizer.step()
+    return loss.detach(), loss_end.detach(), dyn_res

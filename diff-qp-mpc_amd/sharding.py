@@ -48,6 +48,36 @@ def gather_solution(z_local, nbatch, group=None):
     return torch.cat(parts, 0)
 
 
+class _GatherWithGrad(torch.autograd.Function):
+    """gather_solution with a backward: a loss taken on the gathered batch sends every rank the
+    cotangent slice of its own shard (each rank evaluates the same loss on the same gathered
+    tensor, so no reduction is needed -- the slices of other ranks belong to their own graphs)."""
+
+    @staticmethod
+    def forward(ctx, z_local, nbatch, group):
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ctx.bounds = shard_bounds(nbatch, world, rank)
+        return gather_solution(z_local.detach(), nbatch, group)
+
+    @staticmethod
+    def backward(ctx, g):
+        lo, hi = ctx.bounds
+        return g[lo:hi].contiguous(), None, None
+
+
+def gather_solution_autograd(z_local, nbatch, group=None):
+    """Differentiable form of gather_solution (use when the loss is a function of the full batch)."""
+    return _GatherWithGrad.apply(z_local, nbatch, group)
+
+
+def reduce_shared_grad_from_local_mean(g_local_mean, n_local, nbatch, group=None):
+    """QPFunction.backward hands back the LOCAL `.mean(0)` for a parameter shared by the batch
+    (qp.py:160-178 semantics on this rank's shard).  The reference's value on the full batch is the
+    mean over all nbatch samples: weight every rank's mean by its shard size (ragged shards
+    included), sum, divide by nbatch."""
+    return reduce_shared_grad(g_local_mean * float(n_local), nbatch, group)
+
+
 def reduce_shared_grad(g_local_sum, nbatch, group=None):
     """g_local_sum: SUM over the local shard of per-sample gradients of a shared parameter."""
     g = g_local_sum.clone()
@@ -60,4 +90,6 @@ def solve_sharded(solve_fn, params, dims=(3, 2, 3, 2, 3, 2), group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     local, (lo, hi, nbatch) = shard_params(params, dims, world, rank)
     z_local = solve_fn(*local)
+    if z_local.requires_grad:
+        return gather_solution_autograd(z_local, nbatch, group), (lo, hi)
     return gather_solution(z_local, nbatch, group), (lo, hi)

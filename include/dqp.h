@@ -66,6 +66,11 @@ enum {
                                       whose best iterate came later are re-solved up to there.  Needs
                                       the `termination` buffer (dqp_termination_bytes).  Without the
                                       flag a problem stops on its own (see dqp_qp_forward).        */
+#define DQP_FLAG_HISTORY_ONLY 32u   /* with DQP_FLAG_BATCH_TERMINATION: stop after pass 1 (every problem
+                                      iterated to max_iter, (resid, mu) history recorded in
+                                      `termination` as (max_iter, nbatch, 2) doubles, best iterate over
+                                      all max_iter iterations returned): diagnostics and profiling of
+                                      the dominant launch on its own                                */
 #define DQP_FLAG_NO_NULLSPACE 4u   /* forward: keep the equality rows in the iteration even when a
                                       workspace is given (the kernel used without one)       */
 

@@ -1,0 +1,79 @@
+"""GPU parity of the DEQ-MPC call pattern: diff_qp_mpc_amd.policies against the
+reference's deqmpc/policies.py DEQMPCPolicy on its pendulum environment with the same weights
+(tests/golden/DEQMPC_pendulum_T5_b6.npz, make_golden_deqmpc.py): every DEQ round's network
+reference, MPC states and actions (the network runs in float32: rtol 1e-3 / atol 2e-4), the L1 loss
+over all rounds (rtol 1e-4) and its gradients wrt the DEQLayer parameters (rtol 2e-2 / atol 2e-3 of
+the largest entry: float32 network, gradients through three AL solves)."""
+import argparse
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def make_policy(g, B, solver_type="al"):
+    from diff_qp_mpc_amd import policies
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    dyn = DeviceDynamics("pendulum_euler", dt=float(g["dt"]))
+    env = types.SimpleNamespace(nx=2, nu=1, nq=1, dt=float(g["dt"]), dynamics=dyn, dynamics_derivatives=dyn.jac,
+                                action_space=types.SimpleNamespace(high=g["u_upper"], low=g["u_lower"]))
+    args = argparse.Namespace(T=int(g["T"]), nq=1, hdim=int(g["hdim"]), layer_type="mlp", deq_out_type=1,
+                              policy_out_type=1, deq_iter=int(g["deq_iter"]), solver_type=solver_type, qp_iter=1,
+                              eps=1e-2, warm_start=True, bsz=B, Q=torch.tensor(g["Q"]), R=torch.tensor(g["R"]),
+                              dtype="double", device="cuda")
+    torch.manual_seed(0)
+    policy = policies.DEQMPCPolicy(args, env)
+    sd = {k[2:]: torch.tensor(v) for k, v in g.items() if k.startswith("w_")}
+    policy.model.load_state_dict(sd)                 # the reference's own state-dict keys
+    return policies, policy
+
+
+def test_deqmpc_policy_vs_reference():
+    g = dict(np.load(os.path.join(GOLDEN, "DEQMPC_pendulum_T5_b6.npz")))
+    B = g["x"].shape[0]
+    policies, policy = make_policy(g, B)
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32, device="cuda")
+    x, gs, ga, mask = f32(g["x"]), f32(g["gt_states"]), f32(g["gt_actions"]), f32(g["mask"])
+    trajs, dyn_res = policy(x, gs, ga, mask, qp_solve=True)
+    assert len(trajs) == int(g["deq_iter"])
+    for i, (net, xs, us) in enumerate(trajs):
+        np.testing.assert_allclose(net.detach().cpu().numpy(), g["it%d_net" % i], rtol=1e-3, atol=2e-4, err_msg="net %d" % i)
+        np.testing.assert_allclose(xs.detach().cpu().numpy(), g["it%d_x" % i], rtol=1e-3, atol=2e-4, err_msg="x %d" % i)
+        np.testing.assert_allclose(us.detach().cpu().numpy(), g["it%d_u" % i], rtol=1e-3, atol=2e-4, err_msg="u %d" % i)
+    loss, loss_end = policies.compute_loss_deqmpc(policy, gs, ga, mask, trajs)
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-4)
+    np.testing.assert_allclose(float(loss_end.detach()), float(g["loss_end"]), rtol=1e-4)
+    policy.zero_grad()
+    loss.backward()
+    for k, p in policy.model.named_parameters():
+        ref = g["g_" + k]
+        got = p.grad.cpu().numpy() if p.grad is not None else np.zeros_like(ref)
+        np.testing.assert_allclose(got, ref, rtol=2e-2, atol=2e-3 * max(np.abs(ref).max(), 1e-3), err_msg=k)
+
+
+@pytest.mark.parametrize("solver_type", ["al", "ip"])
+def test_train_step_lowers_the_loss(solver_type):
+    """A few optimiser steps on one batch through both solver back ends (AL_mpc and the interior
+    point qp_wrapper.MPC with the true-dynamics residual on chip): the imitation loss goes down and
+    every parameter receives a finite gradient.  B = 256 trajectories."""
+    g = dict(np.load(os.path.join(GOLDEN, "DEQMPC_pendulum_T5_b6.npz")))
+    B, T = 256, int(g["T"])
+    policies, policy = make_policy(g, B, solver_type)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(B, 2, device="cuda", generator=gen) - 0.5
+    gs = x[:, None, :] * torch.linspace(1, 0, T, device="cuda")[None, :, None]
+    ga = torch.zeros(B, T, 1, device="cuda")
+    mask = torch.ones(B, T, device="cuda")
+    opt = torch.optim.Adam(policy.model.parameters(), lr=3e-3)
+    losses = []
+    for _ in range(6):
+        loss, loss_end, dyn_res = policies.train_step(policy, opt, x, gs, ga, mask)
+        losses.append(float(loss))
+        assert np.isfinite(losses[-1])
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in policy.model.parameters())
+    assert losses[-1] < losses[0]
