@@ -34,6 +34,11 @@ struct KParams {
     int dynId, dynT, dynN, dynM;
     double dynDt;
     const double *dynX0;
+    // MPC-structured I/O (dqp_mpc_qp_forward / _backward, null-space kernels only): the dense
+    // (Q,p,G,h,A,b) and their gradients are never materialised in HBM.  mC != NULL selects it.
+    const double *mC, *mc, *mF, *mf, *mx0, *mul, *muu;     // time-major inputs (qp_wrapper layout)
+    double *mdC, *mdc, *mdF, *mdf, *mdx0;                  // backward outputs
+    int mn, mm, mT;
 };
 
 constexpr int TERM_HDR = 8;   // int32 header words in front of the redo list

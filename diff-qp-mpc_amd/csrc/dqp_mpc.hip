@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "../../include/dqp.h"
+#include "dqp_dyn_models.h"
 
 namespace {
 
@@ -144,6 +145,100 @@ __global__ __launch_bounds__(256) void assemble_backward_kernel(MpcP P)
     }
 }
 
+// ---- rollout + cost + backtracking line search, one thread per trajectory ------------------------
+// qp_wrapper.MPC.line_search (qp_wrapper.py:417-436) with rollout (:598-611) and compute_cost
+// (:690-692): alpha = 1; up to max_iter rounds: u_try = u + alpha du, x_try = rollout(x0, u_try),
+// cost_try; a sample whose cost dropped below cost(x, u) keeps its alpha, the others get
+// alpha *= decay and try again.  (The reference stops the ROUNDS when every sample improved; a
+// sample that already improved is recomputed with the same alpha, so the outcome per sample is
+// what this loop gives, including the reference's quirk that a sample that never improves returns
+// its last trial together with an alpha decayed once more.)
+constexpr int LS_MAXN = 8, LS_MAXM = 8;
+struct LsP {
+    const double *F, *f, *x0, *x, *u, *du, *C, *c;
+    double *xn, *un, *alpha, *cost;
+    double decay, dt;
+    int B, n, m, T, dyn, max_iter;
+};
+
+template <class Map>
+__device__ __forceinline__ void ls_step(const double *xs, const double *us, double dt, double *out)
+{
+    double xa[Map::NX], ua[Map::NU], o[Map::NX];
+#pragma unroll
+    for (int k = 0; k < Map::NX; ++k) xa[k] = xs[k];
+#pragma unroll
+    for (int k = 0; k < Map::NU; ++k) ua[k] = us[k];
+    Map::template step<double>(xa, ua, dt, o);
+#pragma unroll
+    for (int k = 0; k < Map::NX; ++k) out[k] = o[k];
+}
+
+__device__ __forceinline__ double stage_cost(const LsP &P, long long b, int t, const double *xs, const double *us)
+{
+    const int n = P.n, nt = n + P.m;
+    const double *Ct = P.C + ((long long)t * P.B + b) * nt * nt, *ct = P.c + ((long long)t * P.B + b) * nt;
+    double acc = 0.0;
+    for (int i = 0; i < nt; ++i) {
+        const double ti = i < n ? xs[i] : us[i - n];
+        double row = 0.0;
+        for (int j = 0; j < nt; ++j) row += Ct[i * nt + j] * (j < n ? xs[j] : us[j - n]);
+        acc += ti * (0.5 * row + ct[i]);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(64) void line_search_kernel(LsP P)
+{
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.B) return;
+    const int n = P.n, m = P.m, T = P.T, nt = n + m;
+    double cost_here = 0.0;
+    for (int t = 0; t < T; ++t) {
+        double xs[LS_MAXN], us[LS_MAXM];
+        for (int i = 0; i < n; ++i) xs[i] = P.x[((long long)t * P.B + b) * n + i];
+        for (int i = 0; i < m; ++i) us[i] = P.u[((long long)t * P.B + b) * m + i];
+        cost_here += stage_cost(P, b, t, xs, us);
+    }
+    double alpha = 1.0, cost_try = 0.0;
+    for (int round = 0; round < P.max_iter; ++round) {
+        double xs[LS_MAXN], us[LS_MAXM], nx[LS_MAXN];
+        for (int i = 0; i < n; ++i) xs[i] = P.x0[b * n + i];
+        cost_try = 0.0;
+        for (int t = 0; t < T; ++t) {
+            for (int i = 0; i < m; ++i) {
+                const long long o = ((long long)t * P.B + b) * m + i;
+                us[i] = P.u[o] + P.du[o] * alpha;
+                P.un[o] = us[i];
+            }
+            for (int i = 0; i < n; ++i) P.xn[((long long)t * P.B + b) * n + i] = xs[i];
+            cost_try += stage_cost(P, b, t, xs, us);
+            if (t == T - 1) break;
+            if (P.dyn == 0) {           // LinDx: x+ = F_t [x; u] + f_t
+                const double *Ft = P.F + ((long long)t * P.B + b) * n * nt, *ft = P.f + ((long long)t * P.B + b) * n;
+                for (int i = 0; i < n; ++i) {
+                    double a = ft[i];
+                    for (int j = 0; j < nt; ++j) a += Ft[i * nt + j] * (j < n ? xs[j] : us[j - n]);
+                    nx[i] = a;
+                }
+            } else {
+                switch (P.dyn) {
+                case DQP_DYN_PENDULUM1L: ls_step<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>(xs, us, P.dt, nx); break;
+                case DQP_DYN_CARTPOLE1L: ls_step<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(xs, us, P.dt, nx); break;
+                case DQP_DYN_CARTPOLE2L: ls_step<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(xs, us, P.dt, nx); break;
+                case DQP_DYN_PENDULUM_EULER: ls_step<dqp::dyn::PendulumEuler>(xs, us, P.dt, nx); break;
+                default: ls_step<dqp::dyn::PendulumDx>(xs, us, P.dt, nx); break;
+                }
+            }
+            for (int i = 0; i < n; ++i) xs[i] = nx[i];
+        }
+        if (cost_try < cost_here) break;            // improved: this alpha stands
+        alpha *= P.decay;                           // qp_wrapper.py:431-432
+    }
+    P.alpha[b] = alpha;
+    P.cost[b] = cost_try;
+}
+
 int check(const dqp_mpc_dims *d)
 {
     if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2) return DQP_ERR_BAD_ARG;
@@ -198,6 +293,33 @@ dqp_mpc_assemble_backward(const dqp_mpc_dims *d, const double *dQ, const double 
                                               (P.T - 1) * P.n + P.n);
     hipLaunchKernelGGL(assemble_backward_kernel, dim3(grid_for(total)), dim3(256), 0,
                        (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+__attribute__((visibility("default"))) int
+dqp_mpc_line_search(const dqp_mpc_dims *d, int dyn_id, double dt, const double *F, const double *f,
+                    const double *x0, const double *x, const double *u, const double *delta_u,
+                    const double *C, const double *c, double decay, int32_t max_iter, double *x_new,
+                    double *u_new, double *alpha, double *cost_new, void *stream)
+{
+    int rc = check(d);
+    if (rc) return rc;
+    if (d->nbatch == 0) return DQP_OK;
+    if (d->n_state > LS_MAXN || d->n_ctrl > LS_MAXM) return DQP_ERR_TOO_LARGE;
+    if (!x0 || !x || !u || !delta_u || !C || !c || !x_new || !u_new || !alpha || !cost_new || max_iter < 1)
+        return DQP_ERR_BAD_ARG;
+    if (dyn_id == 0) {
+        if (!F || !f) return DQP_ERR_BAD_ARG;
+    } else {
+        int32_t n = 0, m = 0;
+        if (dqp_dyn_sizes(dyn_id, &n, &m) != DQP_OK || n != d->n_state || m != d->n_ctrl) return DQP_ERR_BAD_ARG;
+    }
+    LsP P = {};
+    P.F = F; P.f = f; P.x0 = x0; P.x = x; P.u = u; P.du = delta_u; P.C = C; P.c = c;
+    P.xn = x_new; P.un = u_new; P.alpha = alpha; P.cost = cost_new;
+    P.decay = decay; P.dt = dt; P.B = d->nbatch; P.n = d->n_state; P.m = d->n_ctrl; P.T = d->T;
+    P.dyn = dyn_id; P.max_iter = max_iter;
+    hipLaunchKernelGGL(line_search_kernel, dim3((P.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 

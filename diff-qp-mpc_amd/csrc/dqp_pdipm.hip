@@ -825,6 +825,84 @@ static int forward_once(const KParams &P, size_t lds, void *workspace, void *str
     return launch(qp_forward_kernel<64>, P, lds, stream);
 }
 
+// MPC-structured entry points: the null-space kernels assemble (Q,p,G,h,A,b) in registers from the
+// time-major MPC data and scatter the gradients back the same way -- no dense QP in HBM.
+static int mpc_params(const dqp_mpc_dims *md, const dqp_opts *opts, KParams &P, size_t &lds)
+{
+    if (!md || md->T < 2 || md->n_state < 1 || md->n_ctrl < 1 || !md->has_bounds) return DQP_ERR_BAD_ARG;
+    dqp_dims d = {};
+    d.nbatch = md->nbatch;
+    d.nz = md->T * (md->n_state + md->n_ctrl);
+    d.nineq = 2 * md->T * md->n_ctrl;
+    d.neq = md->T * md->n_state;
+    int rc = fill_params(&d, opts, P, lds);
+    if (rc != DQP_OK) return rc;
+    if (P.dynId) return DQP_ERR_BAD_ARG;
+    P.mn = md->n_state; P.mm = md->n_ctrl; P.mT = md->T;
+    return r16n_workspace_doubles(P.N, P.M, P.E) > 0 ? DQP_OK : DQP_ERR_TOO_LARGE;
+}
+
+__attribute__((visibility("default"))) int dqp_mpc_qp_supported(const dqp_mpc_dims *md)
+{
+    KParams P = {};
+    size_t lds = 0;
+    return mpc_params(md, nullptr, P, lds) == DQP_OK ? 1 : 0;
+}
+
+__attribute__((visibility("default"))) size_t dqp_mpc_qp_workspace_bytes(const dqp_mpc_dims *md)
+{
+    KParams P = {};
+    size_t lds = 0;
+    if (mpc_params(md, nullptr, P, lds) != DQP_OK || md->nbatch <= 0) return 0;
+    return (size_t)md->nbatch * (size_t)r16n_workspace_doubles(P.N, P.M, P.E) * sizeof(double);
+}
+
+__attribute__((visibility("default"))) int
+dqp_mpc_qp_forward(const dqp_mpc_dims *md, const dqp_opts *opts, const double *C, const double *c,
+                   const double *F, const double *f, const double *x0, const double *u_lower,
+                   const double *u_upper, double *tau, double *lam, double *nu, double *slack,
+                   int32_t *info, double *best_resid, void *workspace, void *termination, void *stream)
+{
+    KParams P = {};
+    size_t lds = 0;
+    int rc = mpc_params(md, opts, P, lds);
+    if (rc != DQP_OK) return rc;
+    if (P.B == 0) return DQP_OK;
+    if (!C || !c || !F || !f || !x0 || !u_lower || !u_upper || !tau || !lam || !nu || !slack || !workspace)
+        return DQP_ERR_BAD_ARG;
+    P.mC = C; P.mc = c; P.mF = F; P.mf = f; P.mx0 = x0; P.mul = u_lower; P.muu = u_upper;
+    P.zhat = tau; P.lam = lam; P.nu = nu; P.slack = slack; P.info = info; P.best_resid = best_resid;
+    P.workspace = (double *)workspace;
+    if (!(P.flags & DQP_FLAG_BATCH_TERMINATION)) return r16n_forward(P, stream);
+    if (!termination || P.maxIter < 1 || P.maxIter > 64) return DQP_ERR_BAD_ARG;
+    P.eps = opts ? opts->eps : 1e-12;
+    term_bind_pass1(P, termination);
+    if ((rc = r16n_forward(P, stream)) != DQP_OK) return rc;
+    if (P.flags & DQP_FLAG_HISTORY_ONLY) return DQP_OK;
+    if ((rc = term_decide(P, termination, stream)) != DQP_OK) return rc;
+    term_bind_pass2(P, termination);
+    return r16n_forward(P, stream);
+}
+
+__attribute__((visibility("default"))) int
+dqp_mpc_qp_backward(const dqp_mpc_dims *md, const dqp_opts *opts, const double *tau, const double *lam,
+                    const double *nu, const double *slack, const double *dl_dtau, double *dC, double *dc,
+                    double *dF, double *df, double *dx0, int32_t *info, void *workspace, void *stream)
+{
+    KParams P = {};
+    size_t lds = 0;
+    int rc = mpc_params(md, opts, P, lds);
+    if (rc != DQP_OK) return rc;
+    if (P.B == 0) return DQP_OK;
+    if (!tau || !lam || !nu || !slack || !dl_dtau || !workspace) return DQP_ERR_BAD_ARG;
+    if (!dC && !dc && !dF && !df && !dx0) return DQP_OK;
+    P.zin = tau; P.lamin = lam; P.nuin = nu; P.slackin = slack; P.gin = dl_dtau;
+    P.mdC = dC; P.mdc = dc; P.mdF = dF; P.mdf = df; P.mdx0 = dx0;
+    P.info = info;
+    P.workspace = (double *)workspace;
+    return r16n_backward(P, stream);
+}
+
 __attribute__((visibility("default"))) int
 dqp_qp_backward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, const double *G,
                 const double *A, const double *zhat, const double *lam, const double *nu,

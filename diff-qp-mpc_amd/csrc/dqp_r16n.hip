@@ -221,6 +221,64 @@ __device__ __forceinline__ void mul_WT(const State<C> &st, const double (&v)[C::
     }
 }
 
+// ---- MPC-structured loaders (qp_wrapper.py:638-679 evaluated in registers): row i of the dense
+// Q / G / A built from the time-major (C, F) of problem qp.  Column c is a compile-time index after
+// unrolling; its knot tc = c / nt and offset jc = c % nt are carried as uniform counters.
+template <int S, int NC>
+__device__ __forceinline__ void mpc_rows_Q(const KParams &P, long long qp, double (&dst)[S][NC], int r)
+{
+    const int nt = P.mn + P.mm;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = r + 16 * s, ic = i < NC ? i : NC - 1;
+        const int t = ic / nt, j = ic - t * nt;
+        const double *row = P.mC + (((long long)t * P.B + qp) * nt + j) * nt;
+        int tc = 0, jc = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double v = row[jc];
+            dst[s][c] = (t == tc && i < NC) ? v : 0.0;
+            if (++jc == nt) { jc = 0; ++tc; }
+        }
+    }
+}
+template <int S, int NC>
+__device__ __forceinline__ void mpc_rows_G(const KParams &P, int nrows, double (&dst)[S][NC], int r)
+{
+    const int n = P.mn, m = P.mm, nt = n + m, half = P.mT * m;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int i = r + 16 * s;
+        const int k = i < half ? i : i - half;
+        const int t = k / m, col = t * nt + n + (k - t * m);
+        const double sg = i < half ? 1.0 : -1.0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) dst[s][c] = (c == col && i < nrows) ? sg : 0.0;
+    }
+}
+template <int S, int NC>
+__device__ __forceinline__ void mpc_rows_A(const KParams &P, long long qp, int nrows, double (&dst)[S][NC], int r)
+{
+    const int n = P.mn, nt = n + P.mm, T = P.mT;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int e = r + 16 * s, ec = e < nrows ? e : nrows - 1;
+        const int t = ec / n, j = ec - t * n;
+        const bool dynrow = t < T - 1;
+        const double *row = P.mF + (((long long)(dynrow ? t : 0) * P.B + qp) * n + j) * nt;
+        int tc = 0, jc = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const double f = row[jc];
+            double v;
+            if (dynrow) v = (tc == t) ? f : ((tc == t + 1 && jc == j) ? -1.0 : 0.0);
+            else v = (tc == 0 && jc == j) ? 1.0 : 0.0;
+            dst[s][c] = e < nrows ? v : 0.0;
+            if (++jc == nt) { jc = 0; ++tc; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 template <class C>
 __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, double *lds, State<C> &st)
@@ -232,15 +290,39 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     // the three right-hand-side vectors are fetched now and consumed in phases D-F, so their HBM
     // latency hides under the factorisations instead of serialising three more round trips
     double p0[SN], h0[SM], b0[SE];
+    const bool mpc = P.mC != nullptr;
+    if (mpc) {      // p = c, h = [u_upper ; -u_lower], b = [-f ; x0]   (qp_wrapper.py:638-679)
+        const int n = P.mn, m = P.mm, nt = n + m, T = P.mT;
 #pragma unroll
-    for (int s = 0; s < SN; ++s) p0[s] = (r + 16 * s < N) ? P.p[qp * P.sp + r + 16 * s] : 0.0;
+        for (int s = 0; s < SN; ++s) {
+            const int i = r + 16 * s, ic = i < N ? i : N - 1, t = ic / nt;
+            const double v = P.mc[((long long)t * P.B + qp) * nt + (ic - t * nt)];
+            p0[s] = i < N ? v : 0.0;
+        }
 #pragma unroll
-    for (int s = 0; s < SM; ++s) h0[s] = (r + 16 * s < M) ? P.h[qp * P.sh + r + 16 * s] : 0.0;
+        for (int s = 0; s < SM; ++s) {
+            const int i = r + 16 * s, k = (i < T * m ? i : i - T * m), ju = (k < T * m ? k : 0) % m;
+            const double v = i < T * m ? P.muu[ju] : -P.mul[ju];
+            h0[s] = i < M ? v : 0.0;
+        }
 #pragma unroll
-    for (int s = 0; s < SE; ++s) b0[s] = (E > 0 && r + 16 * s < E) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
+        for (int s = 0; s < SE; ++s) {
+            const int e = r + 16 * s, ec = e < E ? e : (E > 0 ? E - 1 : 0), t = ec / n, j = ec - t * n;
+            const double v = t < T - 1 ? -P.mf[((long long)t * P.B + qp) * n + j] : P.mx0[qp * n + j];
+            b0[s] = (E > 0 && e < E) ? v : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < SN; ++s) p0[s] = (r + 16 * s < N) ? P.p[qp * P.sp + r + 16 * s] : 0.0;
+#pragma unroll
+        for (int s = 0; s < SM; ++s) h0[s] = (r + 16 * s < M) ? P.h[qp * P.sh + r + 16 * s] : 0.0;
+#pragma unroll
+        for (int s = 0; s < SE; ++s) b0[s] = (E > 0 && r + 16 * s < E) ? P.b[qp * P.sb + r + 16 * s] : 0.0;
+    }
     {   // A: Q -> Lq -> packed LDS
         double Lq[SN][N];
-        load_rows<SN, N>(P.Q + qp * P.sQ, N, Lq, r);
+        if (mpc) mpc_rows_Q<SN, N>(P, qp, Lq, r);
+        else load_rows<SN, N>(P.Q + qp * P.sQ, N, Lq, r);
         if (!chol_rows<SN, N>(Lq, st.rdq, r)) st.status = DQP_STATUS_Q_NOT_PD;
         tri_store<SN, N>(lds + C::oLq, Lq, r, dummy);
     }
@@ -249,8 +331,13 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     STAMP(P, 1);
 
     // B: rows of G, A times Lq^-T (Lq[j][k] read row-uniformly from LDS)
-    load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
-    if (E > 0) load_rows<SE, N>(P.A + qp * P.sA, E, st.Ah, r);
+    if (mpc) {
+        mpc_rows_G<SM, N>(P, M, st.Gh, r);
+        if (E > 0) mpc_rows_A<SE, N>(P, qp, E, st.Ah, r);
+    } else {
+        load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
+        if (E > 0) load_rows<SE, N>(P.A + qp * P.sA, E, st.Ah, r);
+    }
     {
         const double *Lp = lds + C::oLq;
 #pragma unroll
@@ -936,6 +1023,54 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P)
     tri_solve_T<SN, N>(lds + C::oLq, st.rdq, dxh, r);                   // dx = Lq^-T dxh
 
     if (!live) return;
+    if (P.mdc || P.mdC || P.mdF || P.mdf || P.mdx0) {
+        // MPC-structured gradients: the adjoint of the assembly (qp_wrapper.py:638-679) applied on
+        // chip -- only the diagonal blocks of dQ = sym(dx z^T), the F-blocks of dA = dnu z^T + nu dx^T,
+        // df = -db[dynamics rows] = dnu, dx0 = db[initial rows] = -dnu, dc = dp = dx.
+        const int n = P.mn, m = P.mm, nt = n + m, T = P.mT;
+        const long long Bq = P.B;
+        int tl[SN], jl[SN];                     // knot / offset of the lane's own columns
+#pragma unroll
+        for (int s = 0; s < SN; ++s) { const int c = r + 16 * s; tl[s] = c / nt; jl[s] = c - tl[s] * nt; }
+        if (P.mdc) {
+#pragma unroll
+            for (int s = 0; s < SN; ++s)
+                if (inN[s]) P.mdc[((long long)tl[s] * Bq + qp) * nt + jl[s]] = dxh[s];
+        }
+        if (P.mdC) {
+            int ti = 0, ji = 0;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const double dxi = BC(dxh, i), zi = BC(zh, i);
+#pragma unroll
+                for (int s = 0; s < SN; ++s)
+                    if (inN[s] && tl[s] == ti)
+                        P.mdC[(((long long)ti * Bq + qp) * nt + ji) * nt + jl[s]] = 0.5 * (dxi * zh[s] + zi * dxh[s]);
+                if (++ji == nt) { ji = 0; ++ti; }
+            }
+        }
+        if (E > 0) {
+            int te = 0, je = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const double dni = BC(dnu, e), ni = BC(nu, e);
+                if (te < T - 1) {
+                    if (P.mdF) {
+#pragma unroll
+                        for (int s = 0; s < SN; ++s)
+                            if (inN[s] && tl[s] == te)
+                                P.mdF[(((long long)te * Bq + qp) * n + je) * nt + jl[s]] = dni * zh[s] + ni * dxh[s];
+                    }
+                    if (P.mdf && r == 0) P.mdf[((long long)te * Bq + qp) * n + je] = dni;
+                } else if (P.mdx0 && r == 0) {
+                    P.mdx0[qp * n + je] = -dni;
+                }
+                if (++je == n) { je = 0; ++te; }
+            }
+        }
+        if (r == 0 && P.info) { P.info[2 * qp] = st.status; P.info[2 * qp + 1] = 0; }
+        return;
+    }
     // gradients (qp.py:158-181); each lane writes its own rows
 #pragma unroll
     for (int s = 0; s < SN; ++s)

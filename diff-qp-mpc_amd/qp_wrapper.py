@@ -46,6 +46,12 @@ class LinDx(NamedTuple):
     f: Optional[torch.Tensor] = None
 
 
+# single_qp goes through the fused MPC QP entry points (dqp_mpc_qp_*) when the size has a null-space
+# kernel; False forces the assemble + DenseQPFunction pipeline (tests compare the two)
+FUSED_MPC_QP = True
+# line_search (rollouts + costs + backtracking) as one kernel for LinDx / registered device models
+FUSED_LINE_SEARCH = True
+
 # member names and values as in qpth.qp_wrapper.GradMethods
 GradMethods = Enum("GradMethods", ["AUTO_DIFF", "FINITE_DIFF", "ANALYTIC", "ANALYTIC_CHECK"])
 
@@ -122,6 +128,73 @@ class _AssembleDenseQP(Function):
             rc = lib.dqp_mpc_assemble_backward(ctypes.byref(dims), _ptr(dQ), _ptr(dp), _ptr(dA),
                                                _ptr(db), *[_ptr(o) for o in outs], _stream(dev))
         _lib.check(rc, "dqp_mpc_assemble_backward")
+        outs = [None if o is None else o.to(ctx.dtype) for o in outs]
+        return (*outs, None, None, None, None, None)
+
+
+class _MPCQP(Function):
+    """(C, c, F, f, x0) -> tau (B, T, n+m): assembly + DenseQPFunction (qp_wrapper.py:311-319) as ONE
+    solve through dqp_mpc_qp_forward -- the dense (Q,p,G,h,A,b) exists only in registers -- and
+    the backward straight into (dC, dc, dF, df, dx0) (dqp_mpc_qp_backward)."""
+
+    @staticmethod
+    def supported(B, n_state, n_ctrl, T):
+        dims = _lib.dqp_mpc_dims(B, n_state, n_ctrl, T, 1, 0)
+        return bool(_lib.load().dqp_mpc_qp_supported(ctypes.byref(dims)))
+
+    @staticmethod
+    def forward(ctx, C, c, F, f, x0, u_lower, u_upper, n_state, n_ctrl, T):
+        from . import qp as qpmod
+        lib = _lib.load()
+        for t in (C, c, F, f, x0):
+            if not t.is_cuda:
+                raise RuntimeError("diff_qp_mpc_amd.qp_wrapper.MPC runs only on a GPU (HIP); "
+                                   "there is no CPU fallback.")
+        dev, B, nt = x0.device, x0.shape[0], n_state + n_ctrl
+        cv = lambda t: t.detach().double().contiguous()
+        keep = [cv(C), cv(c), cv(F), cv(f), cv(x0), cv(u_lower).reshape(-1), cv(u_upper).reshape(-1)]
+        if keep[5].numel() != n_ctrl or keep[6].numel() != n_ctrl:
+            raise RuntimeError("u_lower/u_upper must have shape (n_ctrl,) (qp_wrapper.py:677-678)")
+        dims = _lib.dqp_mpc_dims(B, n_state, n_ctrl, T, 1, 0)
+        batch = qpmod.TERMINATION == "batch"
+        opts = _lib.dqp_opts(1e-12, qpmod.STALL_TOL, 20, 3, _lib.DQP_FLAG_BATCH_TERMINATION if batch else 0, 0)
+        kw = dict(dtype=torch.float64, device=dev)
+        tau = torch.empty(B, T, nt, **kw)
+        lam = torch.empty(B, 2 * T * n_ctrl, **kw); slack = torch.empty(B, 2 * T * n_ctrl, **kw)
+        nu = torch.empty(B, T * n_state, **kw)
+        info = torch.empty(B, 2, dtype=torch.int32, device=dev)
+        resid = torch.empty(B, **kw)
+        ws = torch.empty(int(lib.dqp_mpc_qp_workspace_bytes(ctypes.byref(dims))) // 8, **kw)
+        qd = _lib.dqp_dims(B, T * nt, 2 * T * n_ctrl, T * n_state, 0, 0, 0, 0, 0, 0)
+        tb = int(lib.dqp_termination_bytes(ctypes.byref(qd), ctypes.byref(opts)))
+        term = torch.empty((tb + 7) // 8, **kw) if tb else None
+        with torch.cuda.device(dev):
+            rc = lib.dqp_mpc_qp_forward(ctypes.byref(dims), ctypes.byref(opts), *[_ptr(t) for t in keep],
+                                        _ptr(tau), _ptr(lam), _ptr(nu), _ptr(slack), _ptr(info), _ptr(resid),
+                                        _ptr(ws), _ptr(term), _stream(dev))
+        _lib.check(rc, "dqp_mpc_qp_forward")
+        ctx.dims, ctx.ws = dims, ws
+        ctx.shapes = (C.shape, c.shape, F.shape, f.shape, x0.shape)
+        ctx.dtype = x0.dtype
+        ctx.save_for_backward(tau, lam, nu, slack)
+        ctx.info, ctx.resid = info, resid
+        return tau.to(x0.dtype)
+
+    @staticmethod
+    def backward(ctx, dtau):
+        lib = _lib.load()
+        tau, lam, nu, slack = ctx.saved_tensors
+        dev = tau.device
+        kw = dict(dtype=torch.float64, device=dev)
+        need = ctx.needs_input_grad
+        outs = [torch.empty(s, **kw) if need[i] else None for i, s in enumerate(ctx.shapes)]
+        g = dtau.detach().double().contiguous()
+        opts = _lib.dqp_opts(0.0, 0.0, 0, 0, _lib.DQP_FLAG_DENSE_BACKWARD, 0)
+        with torch.cuda.device(dev):
+            rc = lib.dqp_mpc_qp_backward(ctypes.byref(ctx.dims), ctypes.byref(opts), _ptr(tau), _ptr(lam),
+                                         _ptr(nu), _ptr(slack), _ptr(g), *[_ptr(o) for o in outs],
+                                         ctypes.c_void_p(0), _ptr(ctx.ws), _stream(dev))
+        _lib.check(rc, "dqp_mpc_qp_backward")
         outs = [None if o is None else o.to(ctx.dtype) for o in outs]
         return (*outs, None, None, None, None, None)
 
@@ -240,6 +313,12 @@ class MPC(Module):
             as_t = lambda v: (torch.full((self.n_ctrl,), float(v), dtype=torch.float64, device=x0.device)
                               if isinstance(v, float) else v.to(x0.device))
             ul, uu = as_t(self.u_lower), as_t(self.u_upper)
+        if (FUSED_MPC_QP and dyn_res is None and not self.add_goal_constraint and ul is not None
+                and _MPCQP.supported(self.n_batch, self.n_state, self.n_ctrl, self.T)):
+            # assembly + QP + (in backward) the assembly's adjoint in one kernel each way
+            tau = _MPCQP.apply(cost.C, cost.c, F, f, x0, ul, uu, self.n_state, self.n_ctrl, self.T)
+            x_qp, u_qp = tau[..., :self.n_state].transpose(0, 1), tau[..., self.n_state:].transpose(0, 1)
+            return x_qp - x, u_qp - u, self.compute_cost(tau, cost)
         Q, q, G, h, A, b = _AssembleDenseQP.apply(cost.C, cost.c, F, f, x0, ul, uu,
                                                   self.n_state, self.n_ctrl, self.T)
         if self.add_goal_constraint:
@@ -260,6 +339,7 @@ class MPC(Module):
         step_x, step_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost)
         with torch.no_grad():
             _, _, alpha, cost_total = self.line_search(x, u, step_x, step_u, dx, x0, cost)
+        self.last_alpha = alpha          # (1, B, 1): the factor the differentiable step was scaled by
         return x + alpha * step_x, u + alpha * step_u, cost_total
 
     # ------------------------------------------------------------------ behaviour of qp_wrapper.py:348-414
@@ -295,6 +375,10 @@ class MPC(Module):
         """Backtracking on the true rollout cost: samples whose cost did not drop get their step
         factor multiplied by linesearch_decay; stops when every sample improved (or after
         max_linesearch_iter rounds).  Returns the last trial (x, u), the factors and its costs."""
+        if (FUSED_LINE_SEARCH and x.is_cuda and isinstance(cost, QuadCost) and cost.C.dim() == 4
+                and (isinstance(dx, DeviceDynamics) or (isinstance(dx, LinDx) and dx.f is not None))
+                and self.n_state <= 8 and self.n_ctrl <= 8):
+            return self._line_search_fused(x, u, delta_u, dx, x0, cost)
         alpha = x0.new_ones(1, self.n_batch, 1)
         cost_here = self.compute_cost(torch.cat((x, u), dim=2).transpose(0, 1), cost)
         for _ in range(self.max_linesearch_iter):
@@ -306,6 +390,28 @@ class MPC(Module):
                 break
             alpha = torch.where(worse[None, :, None], alpha * self.linesearch_decay, alpha)
         return x_try, u_try, alpha, cost_try
+
+    def _line_search_fused(self, x, u, delta_u, dx, x0, cost):
+        """line_search in one launch (dqp_mpc_line_search): rollouts, costs and the per-sample
+        backtracking on the device, no host synchronisation."""
+        lib = _lib.load()
+        dev, B, T, n, m = x0.device, self.n_batch, self.T, self.n_state, self.n_ctrl
+        cv = lambda t: t.detach().double().contiguous()
+        lin = isinstance(dx, LinDx)
+        keep = [cv(dx.F) if lin else None, cv(dx.f) if lin else None, cv(x0), cv(x), cv(u), cv(delta_u),
+                cv(cost.C), cv(cost.c)]
+        kw = dict(dtype=torch.float64, device=dev)
+        x_new, u_new = torch.empty(T, B, n, **kw), torch.empty(T, B, m, **kw)
+        alpha, cost_new = torch.empty(B, **kw), torch.empty(B, **kw)
+        dims = _lib.dqp_mpc_dims(B, n, m, T, 1, 0)
+        with torch.cuda.device(dev):
+            rc = lib.dqp_mpc_line_search(ctypes.byref(dims), 0 if lin else dx.id, 0.0 if lin else dx.dt,
+                                         *[_ptr(t) for t in keep], float(self.linesearch_decay),
+                                         int(self.max_linesearch_iter), _ptr(x_new), _ptr(u_new), _ptr(alpha),
+                                         _ptr(cost_new), _stream(dev))
+        _lib.check(rc, "dqp_mpc_line_search")
+        dt = x0.dtype
+        return x_new.to(dt), u_new.to(dt), alpha.to(dt).reshape(1, B, 1), cost_new.to(dt)
 
     # ------------------------------------------------------------------ behaviour of qp_wrapper.py:481-515
     def linearize_dynamics(self, x, u, dynamics, dx_jac, diff):

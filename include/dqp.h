@@ -199,6 +199,44 @@ int dqp_mpc_assemble_backward(const dqp_mpc_dims *dims, const double *dQ, const 
                               const double *dA, const double *db, double *dC, double *dc,
                               double *dF, double *df, double *dx0, void *stream);
 
+/*
+ * The MPC QP end to end without the dense detour: what qp_wrapper.MPC.single_qp does between
+ * linearize_dynamics and the line search (qp_wrapper.py:311-319: compute_Qq/Ab/Gh_dense +
+ * qp.DenseQPFunction()) in ONE solve launch -- the kernel builds the rows of (Q,p,G,h,A,b) in
+ * registers from (C,c,F,f,x0,bounds) and solves; backward scatters straight into
+ * (dC,dc,dF,df,dx0) (the adjoint of the assembly applied on chip).  HBM traffic per QP at
+ * n=3 m=3 T=5: 0.7 k doubles in instead of 2.3 k, 0.3 k gradient doubles out instead of 2.3 k.
+ * Needs control bounds, a size with a null-space kernel (dqp_mpc_qp_supported) and the workspace
+ * (dqp_mpc_qp_workspace_bytes), which carries the factorisation context from forward to backward.
+ * tau (B, T, n_state+n_ctrl) = the QP solution per knot [x_t, u_t]; lam/nu/slack/info/best_resid and
+ * the termination modes as in dqp_qp_forward; backward = DenseQPFunction's (un-clamped d).
+ */
+int dqp_mpc_qp_supported(const dqp_mpc_dims *dims);
+size_t dqp_mpc_qp_workspace_bytes(const dqp_mpc_dims *dims);
+int dqp_mpc_qp_forward(const dqp_mpc_dims *dims, const dqp_opts *opts, const double *C, const double *c,
+                       const double *F, const double *f, const double *x0, const double *u_lower,
+                       const double *u_upper, double *tau, double *lam, double *nu, double *slack,
+                       int32_t *info, double *best_resid, void *workspace, void *termination,
+                       void *stream);
+int dqp_mpc_qp_backward(const dqp_mpc_dims *dims, const dqp_opts *opts, const double *tau,
+                        const double *lam, const double *nu, const double *slack,
+                        const double *dl_dtau, double *dC, double *dc, double *dF, double *df,
+                        double *dx0, int32_t *info, void *workspace, void *stream);
+
+/*
+ * Replaces: qp_wrapper.MPC.line_search with its rollouts and cost evaluations
+ * (qpth/qp_wrapper.py:417-436, 598-611, 690-692; ~60 torch ops and one host sync per round): backtracking
+ * on the TRUE rollout cost, alpha in {1, decay, decay^2, ...}, per trajectory, in one launch.
+ * Dynamics: dyn_id == 0 -> LinDx (F (T-1,B,n,nt), f (T-1,B,n)), else a registered device model
+ * (DQP_DYN_*, step dt).  x (T,B,n), u (T,B,m): current trajectory; delta_u (T,B,m): the QP step; C, c
+ * the quadratic cost.  Outputs: the last trial x_new, u_new, its cost, and alpha (B) with the
+ * reference's convention (a trajectory that never improved carries one extra decay).
+ */
+int dqp_mpc_line_search(const dqp_mpc_dims *dims, int dyn_id, double dt, const double *F, const double *f,
+                        const double *x0, const double *x, const double *u, const double *delta_u,
+                        const double *C, const double *c, double decay, int32_t max_iter,
+                        double *x_new, double *u_new, double *alpha, double *cost_new, void *stream);
+
 /* ------------------------------------------------------------ augmented-Lagrangian Newton */
 
 typedef struct dqp_al_dims {

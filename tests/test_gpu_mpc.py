@@ -140,15 +140,31 @@ def test_config2_pendulumdx_vs_reference(tag, kw):
     from diff_qp_mpc_amd import qp_wrapper
     g0 = load("CFG2_pendulumdx_T10_b6")
     B, T = g0["x0"].shape[0], 10
-    g, dx, C, c, lo, hi = _cfg2_problem(B, T, g0["x0"])
-    ctrl = qp_wrapper.MPC(3, 1, T, u_lower=lo, u_upper=hi, n_batch=B, max_linesearch_iter=5,
-                          linesearch_decay=0.2, **kw)
-    x, u = ctrl(dev(g["x0"]), qp_wrapper.QuadCost(C, c), dx, dx.jac)
-    np.testing.assert_allclose(x.detach().cpu().numpy(), g[tag + "_x"], rtol=1e-5, atol=1e-7)
-    np.testing.assert_allclose(u.detach().cpu().numpy(), g[tag + "_u"], rtol=1e-5, atol=1e-7)
-    (x.sum() + 2.0 * u.sum()).backward()
-    np.testing.assert_allclose(C.grad.cpu().numpy(), g[tag + "_dC"], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(c.grad.cpu().numpy(), g[tag + "_dc"], rtol=1e-4, atol=1e-6)
+    res = {}
+    for fused in (False, True):
+        # The last line search of the SQP loop starts from a converged iterate: cost_try equals
+        # cost_here up to round-off, so whether a sample keeps alpha = 1 or backtracks to decay^5 is
+        # decided by the summation order of the cost.  The torch path follows the reference's order
+        # (its gradients are compared in full); the fused kernel must reproduce x and u, and the
+        # gradients of every sample whose alpha came out the same.
+        qp_wrapper.FUSED_LINE_SEARCH = fused
+        try:
+            g, dx, C, c, lo, hi = _cfg2_problem(B, T, g0["x0"])
+            ctrl = qp_wrapper.MPC(3, 1, T, u_lower=lo, u_upper=hi, n_batch=B, max_linesearch_iter=5,
+                                  linesearch_decay=0.2, **kw)
+            x, u = ctrl(dev(g["x0"]), qp_wrapper.QuadCost(C, c), dx, dx.jac)
+            np.testing.assert_allclose(x.detach().cpu().numpy(), g[tag + "_x"], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(u.detach().cpu().numpy(), g[tag + "_u"], rtol=1e-5, atol=1e-7)
+            (x.sum() + 2.0 * u.sum()).backward()
+            res[fused] = (ctrl.last_alpha.reshape(-1).cpu().numpy(), C.grad.cpu().numpy(), c.grad.cpu().numpy())
+        finally:
+            qp_wrapper.FUSED_LINE_SEARCH = True
+    np.testing.assert_allclose(res[False][1], g[tag + "_dC"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(res[False][2], g[tag + "_dc"], rtol=1e-4, atol=1e-6)
+    same = np.isclose(res[True][0], res[False][0])
+    assert same.sum() >= B // 2
+    np.testing.assert_allclose(res[True][1][:, same], g[tag + "_dC"][:, same], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(res[True][2][:, same], g[tag + "_dc"][:, same], rtol=1e-4, atol=1e-6)
 
 
 def test_config2_linearised_residual_is_a_different_problem():
@@ -197,3 +213,75 @@ def test_config2_full_size_properties():
     assert float((cost(xs, us) - c0).max()) <= 1e-9
     (x.sum() + u.sum()).backward()
     assert bool(torch.isfinite(C.grad).all()) and bool(torch.isfinite(c.grad).all())
+
+
+@pytest.mark.parametrize("name,n,m,T", CASES)
+def test_fused_mpc_qp_equals_assemble_plus_dense(name, n, m, T):
+    """dqp_mpc_qp_forward / _backward (the dense QP only ever exists in registers) against the
+    assemble -> DenseQPFunction -> assemble-adjoint pipeline on the same inputs: identical kernels
+    underneath, so tau and all five gradients agree to round-off."""
+    from diff_qp_mpc_amd import qp_wrapper
+    g = load(name)
+    B = g["mpc_x0"].shape[0]
+    assert qp_wrapper._MPCQP.supported(B, n, m, T)
+    outs = {}
+    for fused in (True, False):
+        qp_wrapper.FUSED_MPC_QP = fused
+        try:
+            C, c, F, f, x0 = [dev(g["mpc_" + k], grad=True) for k in ("C", "c", "F", "f", "x0")]
+            mpc = qp_wrapper.MPC(n, m, T, u_lower=dev(g["mpc_u_lower"]), u_upper=dev(g["mpc_u_upper"]), n_batch=B,
+                                 verbose=-1, single_qp_solve=True)
+            x, u = mpc(x0, qp_wrapper.QuadCost(C, c), qp_wrapper.LinDx(F, f), None)
+            w = torch.linspace(0.5, 1.5, x.numel(), dtype=torch.float64, device="cuda").reshape(x.shape)
+            ((x * w).sum() + 2.0 * u.sum()).backward()
+            outs[fused] = [t.detach().cpu().numpy() for t in (x, u, C.grad, c.grad, F.grad, f.grad, x0.grad)]
+        finally:
+            qp_wrapper.FUSED_MPC_QP = True
+    for a, b, k in zip(outs[True], outs[False], ("x", "u", "dC", "dc", "dF", "df", "dx0")):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-11, err_msg=k)
+
+
+@pytest.mark.parametrize("kind", ["lindx", "pendulum_dx", "cartpole1l"])
+def test_fused_line_search_equals_torch_path(kind):
+    """dqp_mpc_line_search against the torch restatement of qp_wrapper.py:417-436 (rollout, cost,
+    per-sample backtracking incl. the extra decay of trajectories that never improve): same x_new,
+    u_new, alpha, cost.  Steps are scaled so that some samples accept alpha = 1, some backtrack a few
+    rounds and some exhaust max_linesearch_iter."""
+    from diff_qp_mpc_amd import qp_wrapper
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    B, T = 257, 6
+    gen = torch.Generator().manual_seed(0)
+    rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).cuda()
+    if kind == "lindx":
+        n, m = 3, 2
+        F = (torch.cat([torch.eye(n, dtype=torch.float64), torch.zeros(n, m, dtype=torch.float64)], 1).cuda()
+             + 0.2 * rnd(T - 1, B, n, n + m))
+        dx = qp_wrapper.LinDx(F, 0.1 * rnd(T - 1, B, n))
+        x0 = rnd(B, n)
+    else:
+        dx = DeviceDynamics(kind)
+        n, m = dx.n_state, dx.n_ctrl
+        x0 = rnd(B, n)
+        if kind == "pendulum_dx":
+            x0[:, :2] = torch.nn.functional.normalize(x0[:, :2], dim=1)
+    L = rnd(T, B, n + m, n + m)
+    C = L @ L.transpose(2, 3) + 0.1 * torch.eye(n + m, dtype=torch.float64, device="cuda")
+    c = rnd(T, B, n + m)
+    mpc = qp_wrapper.MPC(n, m, T, u_lower=-torch.ones(m).double().cuda(), u_upper=torch.ones(m).double().cuda(),
+                         n_batch=B, max_linesearch_iter=4, linesearch_decay=0.3)
+    u = 0.3 * rnd(T, B, m)
+    x = mpc.rollout(x0, u, dx)
+    scale = torch.logspace(-3, 1.5, B, dtype=torch.float64, device="cuda")[None, :, None]
+    du = rnd(T, B, m) * scale
+    outs = {}
+    for fused in (True, False):
+        qp_wrapper.FUSED_LINE_SEARCH = fused
+        try:
+            with torch.no_grad():
+                outs[fused] = mpc.line_search(x, u, torch.zeros_like(x), du, dx, x0, qp_wrapper.QuadCost(C, c))
+        finally:
+            qp_wrapper.FUSED_LINE_SEARCH = True
+    alphas = outs[False][2].reshape(-1)
+    assert len(torch.unique(alphas)) >= 4                    # 1, 0.3, 0.09, ..., 0.3^4
+    for a, b, k in zip(outs[True], outs[False], ("x_new", "u_new", "alpha", "cost")):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-10, err_msg=k)
