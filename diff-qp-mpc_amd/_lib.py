@@ -42,7 +42,7 @@ DQP_MAX_DIM = 64
 # every symbol include/dqp.h declares
 SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termination_bytes",
            "dqp_qp_forward", "dqp_qp_backward", "dqp_mpc_assemble", "dqp_mpc_assemble_backward",
-           "dqp_mpc_qp_supported", "dqp_mpc_qp_workspace_bytes", "dqp_mpc_qp_forward", "dqp_mpc_qp_backward", "dqp_mpc_line_search",
+           "dqp_mpc_qp_supported", "dqp_mpc_qp_workspace_bytes", "dqp_mpc_qp_forward", "dqp_mpc_qp_backward", "dqp_mpc_line_search", "dqp_mpc_rollout_backward",
            "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble", "dqp_al_merit",
            "dqp_dyn_sizes", "dqp_dyn_step", "dqp_dyn_jacobian", "dqp_dyn_forward_dynamics",
            "dqp_dyn_forward_derivatives")
@@ -111,6 +111,8 @@ def load():
     lib.dqp_mpc_line_search.restype = ctypes.c_int
     lib.dqp_mpc_line_search.argtypes = ([ctypes.POINTER(dqp_mpc_dims), ctypes.c_int, ctypes.c_double] + [_dp] * 8 +
                                         [ctypes.c_double, ctypes.c_int32] + [_dp] * 5)
+    lib.dqp_mpc_rollout_backward.restype = ctypes.c_int
+    lib.dqp_mpc_rollout_backward.argtypes = [ctypes.POINTER(dqp_mpc_dims), ctypes.c_int, ctypes.c_double] + [_dp] * 9
     lib.dqp_al_newton_step.restype = ctypes.c_int
     lib.dqp_al_newton_step.argtypes = [ctypes.POINTER(dqp_al_dims)] + [_dp] * 8
     lib.dqp_al_chol_solve.restype = ctypes.c_int

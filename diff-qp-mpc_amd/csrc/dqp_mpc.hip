@@ -177,6 +177,7 @@ __device__ __forceinline__ void ls_step(const double *xs, const double *us, doub
 __device__ __forceinline__ double stage_cost(const LsP &P, long long b, int t, const double *xs, const double *us)
 {
     const int n = P.n, nt = n + P.m;
+    if (!P.C) return 0.0;                     // rollout only (dqp_mpc_line_search with C == NULL)
     const double *Ct = P.C + ((long long)t * P.B + b) * nt * nt, *ct = P.c + ((long long)t * P.B + b) * nt;
     double acc = 0.0;
     for (int i = 0; i < nt; ++i) {
@@ -194,7 +195,7 @@ __global__ __launch_bounds__(64) void line_search_kernel(LsP P)
     if (b >= P.B) return;
     const int n = P.n, m = P.m, T = P.T, nt = n + m;
     double cost_here = 0.0;
-    for (int t = 0; t < T; ++t) {
+    for (int t = 0; t < T && P.C; ++t) {
         double xs[LS_MAXN], us[LS_MAXM];
         for (int i = 0; i < n; ++i) xs[i] = P.x[((long long)t * P.B + b) * n + i];
         for (int i = 0; i < m; ++i) us[i] = P.u[((long long)t * P.B + b) * m + i];
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(64) void line_search_kernel(LsP P)
         for (int t = 0; t < T; ++t) {
             for (int i = 0; i < m; ++i) {
                 const long long o = ((long long)t * P.B + b) * m + i;
-                us[i] = P.u[o] + P.du[o] * alpha;
+                us[i] = P.du ? P.u[o] + P.du[o] * alpha : P.u[o];
                 P.un[o] = us[i];
             }
             for (int i = 0; i < n; ++i) P.xn[((long long)t * P.B + b) * n + i] = xs[i];
@@ -237,6 +238,73 @@ __global__ __launch_bounds__(64) void line_search_kernel(LsP P)
     }
     P.alpha[b] = alpha;
     P.cost[b] = cost_try;
+}
+
+// ---- adjoint of the rollout (what autograd derives from qp_wrapper.py:598-611), one thread per
+// trajectory: lam_{T-1} = g_{T-1};  for t = T-2 .. 0:  du_t = Ju_t^T lam_{t+1},
+// lam_t = g_t + Jx_t^T lam_{t+1};  dF_t = lam_{t+1} [x_t; u_t]^T, df_t = lam_{t+1} (LinDx);  dx0 = lam_0.
+struct RbP {
+    const double *F, *x, *u, *g;
+    double *dx0, *du, *dF, *df;
+    double dt;
+    int B, n, m, T, dyn;
+};
+
+template <class Map>
+__device__ __forceinline__ void vjp_step(const double *xs, const double *us, double dt, const double *lam,
+                                         double *gx, double *gu)
+{
+    constexpr int NX = Map::NX, NU = Map::NU, K = NX + NU;
+    using S = dqp::dyn::Dual<K>;
+    S xa[NX], ua[NU], o[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) { xa[k] = S(xs[k]); xa[k].d[k] = 1.0; }
+#pragma unroll
+    for (int k = 0; k < NU; ++k) { ua[k] = S(us[k]); ua[k].d[NX + k] = 1.0; }
+    Map::template step<S>(xa, ua, dt, o);
+#pragma unroll
+    for (int c = 0; c < NX; ++c) { double a = 0.0; for (int r = 0; r < NX; ++r) a += o[r].d[c] * lam[r]; gx[c] = a; }
+#pragma unroll
+    for (int c = 0; c < NU; ++c) { double a = 0.0; for (int r = 0; r < NX; ++r) a += o[r].d[NX + c] * lam[r]; gu[c] = a; }
+}
+
+__global__ __launch_bounds__(64) void rollout_backward_kernel(RbP P)
+{
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= P.B) return;
+    const int n = P.n, m = P.m, T = P.T, nt = n + m;
+    double lam[LS_MAXN], gx[LS_MAXN], gu[LS_MAXM], xs[LS_MAXN], us[LS_MAXM];
+    for (int i = 0; i < n; ++i) lam[i] = P.g[((long long)(T - 1) * P.B + b) * n + i];
+    if (P.du) for (int i = 0; i < m; ++i) P.du[((long long)(T - 1) * P.B + b) * m + i] = 0.0;   // last action unused
+    for (int t = T - 2; t >= 0; --t) {
+        for (int i = 0; i < n; ++i) xs[i] = P.x[((long long)t * P.B + b) * n + i];
+        for (int i = 0; i < m; ++i) us[i] = P.u[((long long)t * P.B + b) * m + i];
+        if (P.dyn == 0) {
+            const double *Ft = P.F + ((long long)t * P.B + b) * n * nt;
+            for (int j = 0; j < nt; ++j) {
+                double a = 0.0;
+                for (int i = 0; i < n; ++i) a += Ft[i * nt + j] * lam[i];
+                if (j < n) gx[j] = a; else gu[j - n] = a;
+            }
+            if (P.dF) {
+                double *dFt = P.dF + ((long long)t * P.B + b) * n * nt;
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < nt; ++j) dFt[i * nt + j] = lam[i] * (j < n ? xs[j] : us[j - n]);
+            }
+            if (P.df) for (int i = 0; i < n; ++i) P.df[((long long)t * P.B + b) * n + i] = lam[i];
+        } else {
+            switch (P.dyn) {
+            case DQP_DYN_PENDULUM1L: vjp_step<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>(xs, us, P.dt, lam, gx, gu); break;
+            case DQP_DYN_CARTPOLE1L: vjp_step<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(xs, us, P.dt, lam, gx, gu); break;
+            case DQP_DYN_CARTPOLE2L: vjp_step<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(xs, us, P.dt, lam, gx, gu); break;
+            case DQP_DYN_PENDULUM_EULER: vjp_step<dqp::dyn::PendulumEuler>(xs, us, P.dt, lam, gx, gu); break;
+            default: vjp_step<dqp::dyn::PendulumDx>(xs, us, P.dt, lam, gx, gu); break;
+            }
+        }
+        if (P.du) for (int i = 0; i < m; ++i) P.du[((long long)t * P.B + b) * m + i] = gu[i];
+        for (int i = 0; i < n; ++i) lam[i] = P.g[((long long)t * P.B + b) * n + i] + gx[i];
+    }
+    if (P.dx0) for (int i = 0; i < n; ++i) P.dx0[b * n + i] = lam[i];
 }
 
 int check(const dqp_mpc_dims *d)
@@ -306,8 +374,10 @@ dqp_mpc_line_search(const dqp_mpc_dims *d, int dyn_id, double dt, const double *
     if (rc) return rc;
     if (d->nbatch == 0) return DQP_OK;
     if (d->n_state > LS_MAXN || d->n_ctrl > LS_MAXM) return DQP_ERR_TOO_LARGE;
-    if (!x0 || !x || !u || !delta_u || !C || !c || !x_new || !u_new || !alpha || !cost_new || max_iter < 1)
-        return DQP_ERR_BAD_ARG;
+    // C == NULL: plain rollout of u (delta_u, x, c may be NULL too; one round, cost reported as 0)
+    if (!x0 || !u || !x_new || !u_new || !alpha || !cost_new || max_iter < 1) return DQP_ERR_BAD_ARG;
+    if (C && (!x || !delta_u || !c)) return DQP_ERR_BAD_ARG;
+    if (!C) max_iter = 1;
     if (dyn_id == 0) {
         if (!F || !f) return DQP_ERR_BAD_ARG;
     } else {
@@ -320,6 +390,29 @@ dqp_mpc_line_search(const dqp_mpc_dims *d, int dyn_id, double dt, const double *
     P.decay = decay; P.dt = dt; P.B = d->nbatch; P.n = d->n_state; P.m = d->n_ctrl; P.T = d->T;
     P.dyn = dyn_id; P.max_iter = max_iter;
     hipLaunchKernelGGL(line_search_kernel, dim3((P.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+__attribute__((visibility("default"))) int
+dqp_mpc_rollout_backward(const dqp_mpc_dims *d, int dyn_id, double dt, const double *F, const double *x,
+                         const double *u, const double *g_x, double *d_x0, double *d_u, double *d_F,
+                         double *d_f, void *stream)
+{
+    int rc = check(d);
+    if (rc) return rc;
+    if (d->nbatch == 0) return DQP_OK;
+    if (d->n_state > LS_MAXN || d->n_ctrl > LS_MAXM) return DQP_ERR_TOO_LARGE;
+    if (!x || !u || !g_x) return DQP_ERR_BAD_ARG;
+    if (dyn_id == 0) {
+        if (!F) return DQP_ERR_BAD_ARG;
+    } else {
+        int32_t n = 0, m = 0;
+        if (dqp_dyn_sizes(dyn_id, &n, &m) != DQP_OK || n != d->n_state || m != d->n_ctrl) return DQP_ERR_BAD_ARG;
+    }
+    RbP P = {};
+    P.F = F; P.x = x; P.u = u; P.g = g_x; P.dx0 = d_x0; P.du = d_u; P.dF = d_F; P.df = d_f;
+    P.dt = dt; P.B = d->nbatch; P.n = d->n_state; P.m = d->n_ctrl; P.T = d->T; P.dyn = dyn_id;
+    hipLaunchKernelGGL(rollout_backward_kernel, dim3((P.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 

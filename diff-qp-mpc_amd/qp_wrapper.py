@@ -199,6 +199,54 @@ class _MPCQP(Function):
         return (*outs, None, None, None, None, None)
 
 
+class _Rollout(Function):
+    """rollout(x0, u, dynamics) as one launch each way (dqp_mpc_line_search with C == NULL;
+    dqp_mpc_rollout_backward)."""
+
+    @staticmethod
+    def forward(ctx, x0, u, F, f, dyn, n, m, T):
+        lib = _lib.load()
+        dev, B = x0.device, x0.shape[0]
+        cv = lambda t: t.detach().double().contiguous()
+        lin = dyn is None
+        keep = [cv(F) if lin else None, cv(f) if lin else None, cv(x0), None, cv(u), None, None, None]
+        kw = dict(dtype=torch.float64, device=dev)
+        x_new, u_new = torch.empty(T, B, n, **kw), torch.empty(T, B, m, **kw)
+        alpha, cost_new = torch.empty(B, **kw), torch.empty(B, **kw)
+        dims = _lib.dqp_mpc_dims(B, n, m, T, 1, 0)
+        with torch.cuda.device(dev):
+            rc = lib.dqp_mpc_line_search(ctypes.byref(dims), 0 if lin else dyn.id, 0.0 if lin else dyn.dt,
+                                         *[_ptr(t) for t in keep], 1.0, 1, _ptr(x_new), _ptr(u_new), _ptr(alpha),
+                                         _ptr(cost_new), _stream(dev))
+        _lib.check(rc, "dqp_mpc_line_search")
+        ctx.dims, ctx.dyn, ctx.dtype = dims, dyn, x0.dtype
+        ctx.shapes = (F.shape if lin else None, f.shape if lin else None)
+        ctx.save_for_backward(x_new, u_new, keep[0] if lin else x_new)
+        return x_new.to(x0.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        x, u, F = ctx.saved_tensors
+        dyn, dims = ctx.dyn, ctx.dims
+        lin = dyn is None
+        dev = x.device
+        kw = dict(dtype=torch.float64, device=dev)
+        need = ctx.needs_input_grad
+        g64 = g.detach().double().contiguous()
+        d_x0 = torch.empty(dims.nbatch, dims.n_state, **kw) if need[0] else None
+        d_u = torch.empty(dims.T, dims.nbatch, dims.n_ctrl, **kw) if need[1] else None
+        d_F = torch.empty(ctx.shapes[0], **kw) if (lin and need[2]) else None
+        d_f = torch.empty(ctx.shapes[1], **kw) if (lin and need[3]) else None
+        with torch.cuda.device(dev):
+            rc = lib.dqp_mpc_rollout_backward(ctypes.byref(dims), 0 if lin else dyn.id, 0.0 if lin else dyn.dt,
+                                              _ptr(F) if lin else ctypes.c_void_p(0), _ptr(x), _ptr(u), _ptr(g64),
+                                              _ptr(d_x0), _ptr(d_u), _ptr(d_F), _ptr(d_f), _stream(dev))
+        _lib.check(rc, "dqp_mpc_rollout_backward")
+        cvt = lambda t: None if t is None else t.to(ctx.dtype)
+        return cvt(d_x0), cvt(d_u), cvt(d_F), cvt(d_f), None, None, None, None
+
+
 class MPC(Module):
     """Differentiable box-constrained MPC via dense QPs (qpth/qp_wrapper.py:59-211).
 
@@ -284,8 +332,9 @@ class MPC(Module):
         return x, u
 
     # ------------------------------------------------------------------ behaviour of qp_wrapper.py:298-324
-    def single_qp(self, x, u, dx, dx_jac, x0, cost):
-        """One QP around (x, u): returns the step (dx, du) to the QP solution and its cost."""
+    def single_qp(self, x, u, dx, dx_jac, x0, cost, need_cost=True):
+        """One QP around (x, u): returns the step (dx, du) to the QP solution and its cost (None with
+        need_cost=False: the callers inside this class never read it)."""
         if self.add_goal_constraint and self.x_goal is not None and bool((torch.as_tensor(self.x_goal) != 0).any()):
             # the reference pins the last state to ZERO in b (qp_wrapper.py:650-652) while its dyn_res
             # subtracts self.x_goal (:339-341): inconsistent unless the goal is zero
@@ -318,7 +367,7 @@ class MPC(Module):
             # assembly + QP + (in backward) the assembly's adjoint in one kernel each way
             tau = _MPCQP.apply(cost.C, cost.c, F, f, x0, ul, uu, self.n_state, self.n_ctrl, self.T)
             x_qp, u_qp = tau[..., :self.n_state].transpose(0, 1), tau[..., self.n_state:].transpose(0, 1)
-            return x_qp - x, u_qp - u, self.compute_cost(tau, cost)
+            return x_qp - x, u_qp - u, (self.compute_cost(tau, cost) if need_cost else None)
         Q, q, G, h, A, b = _AssembleDenseQP.apply(cost.C, cost.c, F, f, x0, ul, uu,
                                                   self.n_state, self.n_ctrl, self.T)
         if self.add_goal_constraint:
@@ -332,11 +381,11 @@ class MPC(Module):
             b = torch.cat([b, torch.zeros(self.n_batch, n, dtype=b.dtype, device=b.device)], 1)
         tau = DenseQPFunction()(Q, q, G, h, A, b, dyn_res).to(x0.dtype).reshape(self.n_batch, self.T, -1)
         x_qp, u_qp = tau[..., :self.n_state].transpose(0, 1), tau[..., self.n_state:].transpose(0, 1)
-        return x_qp - x, u_qp - u, self.compute_cost(tau, cost)
+        return x_qp - x, u_qp - u, (self.compute_cost(tau, cost) if need_cost else None)
 
     def _damped_step(self, x, u, dx, dx_jac, x0, cost):
         """QP step at (x, u) scaled by the line-search factor (the differentiable last step)."""
-        step_x, step_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost)
+        step_x, step_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost, need_cost=False)
         with torch.no_grad():
             _, _, alpha, cost_total = self.line_search(x, u, step_x, step_u, dx, x0, cost)
         self.last_alpha = alpha          # (1, B, 1): the factor the differentiable step was scaled by
@@ -352,7 +401,7 @@ class MPC(Module):
         with torch.no_grad():
             for _ in range(self.qp_iter):
                 u_before = u
-                step_x, step_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost)
+                step_x, step_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost, need_cost=False)
                 x, u, _, cost_now = self.line_search(x, u, step_x, step_u, dx, x0, cost)
                 if keep_cost is None:
                     keep_x, keep_u, keep_cost = x.clone(), u.clone(), cost_now.clone()
@@ -454,6 +503,11 @@ class MPC(Module):
     # ------------------------------------------------------------------ behaviour of qp_wrapper.py:598-611
     def rollout(self, x, actions, dynamics):
         """States (T,B,n) reached from x under `actions` (T,B,m); the last action is unused."""
+        if (FUSED_LINE_SEARCH and x.is_cuda and self.n_state <= 8 and self.n_ctrl <= 8
+                and (isinstance(dynamics, DeviceDynamics) or (isinstance(dynamics, LinDx) and dynamics.f is not None))):
+            if isinstance(dynamics, LinDx):
+                return _Rollout.apply(x, actions, dynamics.F, dynamics.f, None, self.n_state, self.n_ctrl, self.T)
+            return _Rollout.apply(x, actions, None, None, dynamics, self.n_state, self.n_ctrl, self.T)
         states = [x]
         linear = isinstance(dynamics, LinDx)
         for t in range(self.T - 1):
@@ -481,3 +535,78 @@ class MPC(Module):
         """Total quadratic cost of batch-major trajectories xu (B,T,n+m) under time-major (C, c)."""
         Cx = torch.matmul(cost.C.transpose(0, 1), xu[..., None])[..., 0]          # (B,T,n+m)
         return (xu * (0.5 * Cx + cost.c.transpose(0, 1))).sum(dim=(1, 2))
+
+
+class _GraphReplay(Function):
+    @staticmethod
+    def forward(ctx, g, *inputs):
+        for dst, src in zip(g.static_inputs, inputs):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        g.fwd_graph.replay()
+        ctx.g = g
+        return tuple(o.detach() for o in g.static_outputs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g = ctx.g
+        for dst, src in zip(g.static_grad_outputs, grads):
+            dst.copy_(src if src is not None else torch.zeros_like(dst))
+        g.bwd_graph.replay()
+        return (None,) + tuple(None if gi is None else gi.detach() for gi in g.static_grad_inputs)
+
+
+class GraphedMPC:
+    """`mpc` (single_qp_solve) captured in two hipGraphs -- forward, and backward through the solver's
+    implicit derivative -- sharing one memory pool.  The C-ABI entry points only enqueue on the
+    current stream, allocate nothing and never synchronise, so a call is two graph launches instead
+    of ~100 Python-dispatched ones.  Shapes, dtypes and the batch size are frozen at capture; inputs
+    are copied into the graph's static buffers (pass the same tensors to skip the copy)."""
+
+    def __init__(self, mpc, sample_inputs, dx_factory=None, warmup=3):
+        if not mpc.single_qp_solve:
+            raise NotImplementedError("SQP mode keeps a host test per round (qp_wrapper.py:392): not capturable")
+        self.mpc, self.dx_factory = mpc, dx_factory
+        self.static_inputs = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in sample_inputs)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                outs = self._call(*self.static_inputs)
+                torch.autograd.grad(outs, self._grad_inputs(), tuple(torch.ones_like(o) for o in outs),
+                                    allow_unused=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph, pool=pool):
+            self.static_outputs = self._call(*self.static_inputs)
+        self.static_grad_outputs = tuple(torch.zeros_like(o) for o in self.static_outputs)
+        with torch.cuda.graph(self.bwd_graph, pool=pool):
+            gi = torch.autograd.grad(self.static_outputs, self._grad_inputs(), self.static_grad_outputs,
+                                     allow_unused=True)
+        it = iter(gi)
+        self.static_grad_inputs = tuple(next(it) if t.requires_grad else None for t in self.static_inputs)
+
+    def _grad_inputs(self):
+        return tuple(t for t in self.static_inputs if t.requires_grad)
+
+    def _call(self, *args):
+        if self.dx_factory is None:
+            x0, C, c, F, f = args
+            return self.mpc(x0, QuadCost(C, c), LinDx(F, f), None)
+        x0, C, c = args
+        dx, dx_jac = self.dx_factory()
+        return self.mpc(x0, QuadCost(C, c), dx, dx_jac)
+
+    def __call__(self, *inputs):
+        return _GraphReplay.apply(self, *inputs)
+
+
+def graphed_mpc(mpc, sample_inputs, dx_factory=None):
+    """GraphedMPC(mpc, sample_inputs[, dx_factory]):
+
+        g = graphed_mpc(mpc, (x0, C, c, F, f));   x, u = g(x0, C, c, F, f)            # LinDx
+        g = graphed_mpc(mpc, (x0, C, c), lambda: (dyn, dyn.jac))                        # device model
+    """
+    return GraphedMPC(mpc, sample_inputs, dx_factory)

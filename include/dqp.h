@@ -231,11 +231,24 @@ int dqp_mpc_qp_backward(const dqp_mpc_dims *dims, const dqp_opts *opts, const do
  * (DQP_DYN_*, step dt).  x (T,B,n), u (T,B,m): current trajectory; delta_u (T,B,m): the QP step; C, c
  * the quadratic cost.  Outputs: the last trial x_new, u_new, its cost, and alpha (B) with the
  * reference's convention (a trajectory that never improved carries one extra decay).
+ * With C == NULL (then x, delta_u, c may be NULL) the call is the plain rollout of u from x0
+ * (qp_wrapper.py:598-611): x_new = states, u_new = u.
  */
 int dqp_mpc_line_search(const dqp_mpc_dims *dims, int dyn_id, double dt, const double *F, const double *f,
                         const double *x0, const double *x, const double *u, const double *delta_u,
                         const double *C, const double *c, double decay, int32_t max_iter,
                         double *x_new, double *u_new, double *alpha, double *cost_new, void *stream);
+
+/*
+ * Adjoint of the rollout x_{t+1} = f(x_t, u_t) (what autograd derives from qp_wrapper.py:598-611):
+ * x (T,B,n) the rolled-out states, u (T,B,m), g_x (T,B,n) the cotangent of the states; outputs
+ * d_x0 (B,n), d_u (T,B,m), and for LinDx (dyn_id == 0) d_F (T-1,B,n,nt), d_f (T-1,B,n).  Any output
+ * may be NULL.  Registered models differentiate through the same forward-mode templates as
+ * dqp_dyn_jacobian.
+ */
+int dqp_mpc_rollout_backward(const dqp_mpc_dims *dims, int dyn_id, double dt, const double *F,
+                             const double *x, const double *u, const double *g_x, double *d_x0,
+                             double *d_u, double *d_F, double *d_f, void *stream);
 
 /* ------------------------------------------------------------ augmented-Lagrangian Newton */
 

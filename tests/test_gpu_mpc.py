@@ -285,3 +285,97 @@ def test_fused_line_search_equals_torch_path(kind):
     assert len(torch.unique(alphas)) >= 4                    # 1, 0.3, 0.09, ..., 0.3^4
     for a, b, k in zip(outs[True], outs[False], ("x_new", "u_new", "alpha", "cost")):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-10, err_msg=k)
+
+
+@pytest.mark.parametrize("kind", ["lindx", "pendulum_dx"])
+def test_mpc_call_captured_in_hipgraphs(kind):
+    """qp_wrapper.MPC (single-QP mode) replayed from two hipGraphs (forward; backward through the
+    solver) gives bitwise the eager results on the capture inputs and follows new inputs."""
+    from diff_qp_mpc_amd import qp_wrapper
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    B, T = 64, 5
+    gen = torch.Generator().manual_seed(1)
+    rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).cuda()
+    if kind == "lindx":
+        n, m = 3, 3
+        F = (torch.cat([torch.eye(n), torch.zeros(n, m)], 1).double().cuda() + 0.2 * rnd(T - 1, B, n, n + m))
+        extra = (F.requires_grad_(), (0.1 * rnd(T - 1, B, n)).requires_grad_())
+        factory, lim = None, 1.0
+    else:
+        dyn = DeviceDynamics("pendulum_dx")
+        n, m, T = 3, 1, 10
+        extra, factory, lim = (), (lambda: (dyn, dyn.jac)), 2.0
+    C = (torch.eye(n + m, dtype=torch.float64).repeat(T, B, 1, 1).cuda() * 0.5).requires_grad_()
+
+    def inputs(seed):
+        g2 = torch.Generator().manual_seed(seed)
+        x0 = torch.randn(B, n, generator=g2, dtype=torch.float64).cuda()
+        if kind != "lindx":
+            x0[:, :2] = torch.nn.functional.normalize(x0[:, :2], dim=1)
+        c = torch.randn(T, B, n + m, generator=g2, dtype=torch.float64).cuda()
+        return x0.requires_grad_(), c.requires_grad_()
+
+    one = torch.full((m,), lim, dtype=torch.float64, device="cuda")
+    mpc = qp_wrapper.MPC(n, m, T, u_lower=-one, u_upper=one, n_batch=B, verbose=-1, single_qp_solve=True,
+                         max_linesearch_iter=5)
+
+    def eager(x0, c):
+        if factory is None:
+            return mpc(x0, qp_wrapper.QuadCost(C, c), qp_wrapper.LinDx(*extra), None)
+        d, j = factory()
+        return mpc(x0, qp_wrapper.QuadCost(C, c), d, j)
+
+    x0a, ca = inputs(2)
+    sample = (x0a, C, ca) + extra
+    g = qp_wrapper.graphed_mpc(mpc, sample, factory)
+    for seed in (2, 3):
+        x0, c = inputs(seed)
+        xe, ue = eager(x0, c)
+        ge = torch.autograd.grad((xe * 1.5).sum() + ue.sum(), (x0, c))
+        xg, ug = g(x0, C, c, *extra)
+        gg = torch.autograd.grad((xg * 1.5).sum() + ug.sum(), (x0, c))
+        assert torch.equal(xg, xe) and torch.equal(ug, ue)
+        for a, b in zip(gg, ge):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kind", ["lindx", "cartpole1l", "pendulum_dx"])
+def test_fused_rollout_and_its_adjoint(kind):
+    """MPC.rollout through dqp_mpc_line_search (C == NULL) / dqp_mpc_rollout_backward against the
+    step-by-step torch rollout of qp_wrapper.py:598-611 and its autograd: states 1e-12, gradients wrt
+    x0, u (and F, f for LinDx) 1e-10."""
+    from diff_qp_mpc_amd import qp_wrapper
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    B, T = 33, 7
+    gen = torch.Generator().manual_seed(4)
+    rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).cuda()
+    if kind == "lindx":
+        n, m = 4, 2
+        F0 = torch.cat([torch.eye(n), torch.zeros(n, m)], 1).double().cuda() + 0.2 * rnd(T - 1, B, n, n + m)
+        f0 = 0.1 * rnd(T - 1, B, n)
+        x0v = rnd(B, n)
+    else:
+        dyn = DeviceDynamics(kind)
+        n, m = dyn.n_state, dyn.n_ctrl
+        x0v = rnd(B, n)
+        if kind == "pendulum_dx":
+            x0v[:, :2] = torch.nn.functional.normalize(x0v[:, :2], dim=1)
+    uv, w = 0.5 * rnd(T, B, m), rnd(T, B, n)
+    mpc = qp_wrapper.MPC(n, m, T, u_lower=-torch.ones(m).double().cuda(), u_upper=torch.ones(m).double().cuda(), n_batch=B)
+    res = {}
+    for fused in (True, False):
+        qp_wrapper.FUSED_LINE_SEARCH = fused
+        try:
+            x0, u = x0v.clone().requires_grad_(), uv.clone().requires_grad_()
+            if kind == "lindx":
+                F, f = F0.clone().requires_grad_(), f0.clone().requires_grad_()
+                dx, leaves = qp_wrapper.LinDx(F, f), (x0, u, F, f)
+            else:
+                dx, leaves = dyn, (x0, u)
+            xs = mpc.rollout(x0, u, dx)
+            res[fused] = [xs.detach()] + list(torch.autograd.grad((xs * w).sum(), leaves))
+        finally:
+            qp_wrapper.FUSED_LINE_SEARCH = True
+    np.testing.assert_allclose(res[True][0].cpu().numpy(), res[False][0].cpu().numpy(), rtol=1e-12, atol=1e-12)
+    for a, b in zip(res[True][1:], res[False][1:]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-10)
