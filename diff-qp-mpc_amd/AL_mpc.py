@@ -15,6 +15,10 @@ from torch.nn import Module
 
 from . import al_utils
 from .al_utils import QuadCost, LinDx  # noqa: F401  (re-exported like the reference module)
+from .dynamics import DeviceDynamics
+
+# registered device models run NewtonAL's four Newton steps as one C-ABI call (no Python in between)
+FUSED_NEWTON_AL = True
 
 
 def _detach(t):
@@ -104,13 +108,22 @@ class MPC(Module):
         for _ in range(self.al_iter):
             xu = torch.cat((x, u), dim=2).detach().clone()
             rho_i = rho
-            out, status = al_utils.NewtonAL.apply(
-                lambda xi, Qi, qi, yi, x0i=x0, rhoi=rho_i, grad=False:
-                    self.merit_function(xi, Qi, qi, dx, x0i, yi, rhoi, grad),
-                lambda xi: self.dyn_res(xi, dx, x0),
-                lambda xi, Qi, qi: self.compute_cost(xi, Qi, qi),
-                lambda xi, Qi, qi, yi: self.merit_grad_hess(xi, Qi, qi, dx, dx_jac, x0, yi, rho_i),
-                xu, x0, lamda, rho, Q, q, 1e-3, 1e-6, True)
+            def general(Qg, qg, xu=xu, lamda=lamda, rho=rho, rho_i=rho_i):
+                return al_utils.NewtonAL.apply(
+                    lambda xi, Qi, qi, yi, x0i=x0, rhoi=rho_i, grad=False:
+                        self.merit_function(xi, Qi, qi, dx, x0i, yi, rhoi, grad),
+                    lambda xi: self.dyn_res(xi, dx, x0),
+                    lambda xi, Qi, qi: self.compute_cost(xi, Qi, qi),
+                    lambda xi, Qi, qi, yi: self.merit_grad_hess(xi, Qi, qi, dx, dx_jac, x0, yi, rho_i),
+                    xu, x0, lamda, rho, Qg, qg, 1e-3, 1e-6, True)
+            if (FUSED_NEWTON_AL and isinstance(dx, DeviceDynamics) and self.n_state <= 8 and self.n_ctrl <= 2
+                    and self.T * (self.n_state + self.n_ctrl) <= 128 and self.x_lower is None
+                    and self.u_lower.numel() == self.n_ctrl and torch.is_tensor(rho)):
+                # registered device model: the four Newton steps in one C-ABI call (dqp_al_newton_solve)
+                out, status = al_utils.NewtonALDevice.apply(xu, x0, lamda, rho, Q, q, dx, self.u_lower,
+                                                            self.u_upper, general)
+            else:
+                out, status = general(Q, q)
             x, u = out[:, :, :self.n_state], out[:, :, self.n_state:]
             with torch.no_grad():
                 res, res_clamp = self.dyn_res(torch.cat((x, u), dim=2), dx, x0, res_type='both')

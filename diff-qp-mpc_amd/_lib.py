@@ -44,6 +44,7 @@ SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termin
            "dqp_qp_forward", "dqp_qp_backward", "dqp_mpc_assemble", "dqp_mpc_assemble_backward",
            "dqp_mpc_qp_supported", "dqp_mpc_qp_workspace_bytes", "dqp_mpc_qp_forward", "dqp_mpc_qp_backward", "dqp_mpc_line_search", "dqp_mpc_rollout_backward",
            "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble", "dqp_al_merit",
+           "dqp_al_newton_solve_bytes", "dqp_al_newton_solve",
            "dqp_dyn_sizes", "dqp_dyn_step", "dqp_dyn_jacobian", "dqp_dyn_forward_dynamics",
            "dqp_dyn_forward_derivatives")
 DQP_DYN = {"pendulum1l": 1, "cartpole1l": 2, "cartpole2l": 3, "pendulum_euler": 4, "pendulum_dx": 5}
@@ -121,6 +122,11 @@ def load():
     lib.dqp_al_assemble.argtypes = [ctypes.POINTER(dqp_al_mpc_dims)] + [_dp] * 8
     lib.dqp_al_merit.restype = ctypes.c_int
     lib.dqp_al_merit.argtypes = [ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int32] + [_dp] * 11
+    lib.dqp_al_newton_solve_bytes.restype = ctypes.c_size_t
+    lib.dqp_al_newton_solve_bytes.argtypes = [ctypes.POINTER(dqp_al_mpc_dims)]
+    lib.dqp_al_newton_solve.restype = ctypes.c_int
+    lib.dqp_al_newton_solve.argtypes = ([ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int, ctypes.c_double, ctypes.c_int32]
+                                        + [_dp] * 13)
     i32p = ctypes.POINTER(ctypes.c_int32)
     lib.dqp_dyn_sizes.restype = ctypes.c_int
     lib.dqp_dyn_sizes.argtypes = [ctypes.c_int, i32p, i32p]

@@ -341,6 +341,53 @@ class NewtonAL(torch.autograd.Function):
         return (None,) * 8 + (g * x, g, None, None, None)
 
 
+class NewtonALDevice(torch.autograd.Function):
+    """NewtonAL for a dynamics.DeviceDynamics: the four Newton steps as one C-ABI call
+    (dqp_al_newton_solve: 21 launches, no host involvement); backward as NewtonAL's.  `slow` is a
+    zero-argument callable that runs the general path (NewtonAL.apply with the Python closures): it
+    is used when a Cholesky factorisation breaks down, where the reference switches the batch to an
+    LU solve (al_utils.py:419-427)."""
+
+    @staticmethod
+    def forward(ctx, xi, x0, lam, rho, Q, q, dyn, u_lower, u_upper, slow):
+        lib = _lib.load()
+        B, T, nt = xi.shape
+        n, m = dyn.n_state, dyn.n_ctrl
+        dev = xi.device
+        d64 = lambda t: t.detach().double().contiguous()
+        xu = d64(xi).clone()
+        keep = [d64(x0), d64(Q), d64(q), d64(lam), d64(rho).reshape(B), d64(u_lower).reshape(-1), d64(u_upper).reshape(-1)]
+        dims = _lib.dqp_al_mpc_dims(B, n, m, T)
+        kw = dict(dtype=torch.float64, device=dev)
+        L = torch.empty(B, T * nt, T * nt, **kw)
+        status = torch.empty(B, **kw)
+        fail = torch.zeros(1, dtype=torch.int32, device=dev)
+        ws = torch.empty(int(lib.dqp_al_newton_solve_bytes(ctypes.byref(dims))) // 8 + 1, **kw)
+        with torch.cuda.device(dev):
+            rc = lib.dqp_al_newton_solve(ctypes.byref(dims), dyn.id, dyn.dt, MAX_NEWTON_STEPS, *[_ptr(t) for t in keep],
+                                         _ptr(xu), _ptr(L), _ptr(status), _ptr(fail), _ptr(ws), _stream(dev))
+        _lib.check(rc, "dqp_al_newton_solve")
+        ctx.slow_ctx = None
+        if bool(fail.item()):               # rare: re-run through the general path, incl. its backward
+            with torch.enable_grad():
+                Qs, qs = Q.detach().requires_grad_(), q.detach().requires_grad_()
+                out, st = slow(Qs, qs)
+            ctx.slow_ctx = (out, Qs, qs)
+            return out.detach(), st.detach()
+        ctx.save_for_backward(L, xu)
+        return xu.to(xi.dtype), status.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, x_grad, status_grad):
+        if ctx.slow_ctx is not None:
+            out, Qs, qs = ctx.slow_ctx
+            gQ, gq = torch.autograd.grad(out, (Qs, qs), x_grad)
+            return (None,) * 4 + (gQ, gq) + (None,) * 4
+        L, x = ctx.saved_tensors
+        g = chol_solve_neg(L, x_grad).reshape(x_grad.shape).to(x_grad.dtype)
+        return (None,) * 4 + (g * x.to(x_grad.dtype), g) + (None,) * 4      # al_utils.py:482-485
+
+
 def warm_start_al(x, lamda, rho, cost_start, cost_hist, lam_hist, rho_hist):
     """Pick the multipliers / penalty of the first stored AL iterate whose cost was already below
     the new starting cost; rescale lamda to that iterate's norm (al_utils.py:16-34)."""

@@ -21,7 +21,8 @@
 #include <stdint.h>
 
 #include "../../include/dqp.h"
-#include "dqp_r16_prims.h"   // row_sum (DPP row reduction)
+#include "dqp_r16_prims.h"
+#include "dqp_dyn_models.h"   // row_sum (DPP row reduction)
 
 #ifdef DQP_STAMPS
 namespace dqp { extern unsigned long long *g_debug_stamps; }
@@ -428,6 +429,7 @@ struct AsmP {
     const double *Jx, *Ju, *lam, *resc, *rho;
     double *Jc, *gterm;
     int B, n, m, T;
+    const double *Qd, *q, *xu;       // optional: gterm += Qd * xu + q  (the full merit gradient)
 };
 
 // value of J[row][col] for one problem; act: inequality rows count only when active
@@ -480,6 +482,7 @@ __global__ __launch_bounds__(256) void al_assemble_kernel(AsmP P)
                 const int i = j - n;
                 acc += mu(neq + t * 2 * m + i) - mu(neq + t * 2 * m + m + i);
             }
+            if (P.Qd) acc += P.Qd[b * (long long)nz + col] * P.xu[b * (long long)nz + col] + P.q[b * (long long)nz + col];
             P.gterm[b * (long long)nz + col] = acc;
         }
     }
@@ -526,6 +529,186 @@ __global__ __launch_bounds__(256) void al_merit_kernel(MeritP P)
     }
     acc = dqp::r16::row_sum(acc);
     if (r == 0 && item < total) P.merit[item] = acc;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// NewtonAL with a registered device model: the Python glue of al_utils.NewtonAL.forward
+// (qpth/al_utils.py:363-456, 503-527) as kernels, so that the four Newton steps of one AL iteration
+// are 21 back-to-back launches with no host involvement.
+template <class Map>
+__device__ __forceinline__ void lin_knot(const double *z, double dt, double *xn, double *Jx, double *Ju)
+{
+    constexpr int NX = Map::NX, NU = Map::NU, K = NX + NU;
+    using S = dqp::dyn::Dual<K>;
+    S xa[NX], ua[NU], o[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) { xa[k] = S(z[k]); xa[k].d[k] = 1.0; }
+#pragma unroll
+    for (int k = 0; k < NU; ++k) { ua[k] = S(z[NX + k]); ua[k].d[NX + k] = 1.0; }
+    Map::template step<S>(xa, ua, dt, o);
+#pragma unroll
+    for (int r = 0; r < NX; ++r) {
+        xn[r] = o[r].v;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Jx[r * NX + c] = o[r].d[c];
+#pragma unroll
+        for (int c = 0; c < NU; ++c) Ju[r * NU + c] = o[r].d[NX + c];
+    }
+}
+template <class Map>
+__device__ __forceinline__ void step_knot(const double *xs, const double *us, double dt, double *xn)
+{
+    double xa[Map::NX], ua[Map::NU], o[Map::NX];
+#pragma unroll
+    for (int k = 0; k < Map::NX; ++k) xa[k] = xs[k];
+#pragma unroll
+    for (int k = 0; k < Map::NU; ++k) ua[k] = us[k];
+    Map::template step<double>(xa, ua, dt, o);
+#pragma unroll
+    for (int k = 0; k < Map::NX; ++k) xn[k] = o[k];
+}
+
+struct LinP {
+    const double *xu, *x0, *ul, *uu;
+    double *Jx, *Ju, *resc;
+    double dt;
+    int B, n, m, T, dyn;
+};
+
+// one thread per (problem, knot): dynamics + Jacobians of the knot, its equality rows
+// x_{t+1} - f(x_t, u_t) (or x_0 - x0 for the last block) and its clamped box rows
+__global__ __launch_bounds__(256) void al_linearize_kernel(LinP P)
+{
+    const int n = P.n, m = P.m, T = P.T, nt = n + m, neq = T * n, ncon = neq + 2 * T * m;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)P.B * T) return;
+    const long long b = idx / T;
+    const int t = (int)(idx - b * T);
+    const double *z = P.xu + (b * T + t) * nt;
+    double *resc = P.resc + b * ncon;
+    if (t < T - 1) {
+        double xn[8], Jx[64], Ju[16];
+        switch (P.dyn) {
+        case DQP_DYN_PENDULUM1L: lin_knot<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>(z, P.dt, xn, Jx, Ju); break;
+        case DQP_DYN_CARTPOLE1L: lin_knot<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(z, P.dt, xn, Jx, Ju); break;
+        case DQP_DYN_CARTPOLE2L: lin_knot<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(z, P.dt, xn, Jx, Ju); break;
+        case DQP_DYN_PENDULUM_EULER: lin_knot<dqp::dyn::PendulumEuler>(z, P.dt, xn, Jx, Ju); break;
+        default: lin_knot<dqp::dyn::PendulumDx>(z, P.dt, xn, Jx, Ju); break;
+        }
+        double *oJx = P.Jx + (b * (T - 1) + t) * n * n, *oJu = P.Ju + (b * (T - 1) + t) * n * m;
+        for (int i = 0; i < n * n; ++i) oJx[i] = Jx[i];
+        for (int i = 0; i < n * m; ++i) oJu[i] = Ju[i];
+        for (int i = 0; i < n; ++i) resc[t * n + i] = z[nt + i] - xn[i];
+    } else {
+        const double *z0 = P.xu + b * T * nt;
+        for (int i = 0; i < n; ++i) resc[(T - 1) * n + i] = z0[i] - P.x0[b * n + i];
+    }
+    for (int i = 0; i < m; ++i) {
+        const double u = z[n + i];
+        resc[neq + t * 2 * m + i] = fmax(u - P.uu[i], 0.0);
+        resc[neq + t * 2 * m + m + i] = fmax(P.ul[i] - u, 0.0);
+    }
+}
+
+struct LsAP {
+    const double *xu, *upd, *x0, *Qd, *q, *lam, *rho, *ul, *uu;
+    double *merit;
+    double dt;
+    int B, n, m, T, ncand, dyn;
+};
+
+// merit (al_utils.py:37-59) of ncand candidates xu + 2^-k upd per problem (x_0 pinned to x0,
+// al_utils.py:515), dynamics evaluated in the kernel; 16 lanes per (candidate, problem).  ncand = 0
+// evaluates the current point (step 0) into merit[b].
+__global__ __launch_bounds__(256) void al_ls_kernel(LsAP P)
+{
+    const int n = P.n, m = P.m, T = P.T, nt = n + m, neq = T * n, ncon = neq + 2 * T * m;
+    const int nc = P.ncand > 0 ? P.ncand : 1;
+    const long long item = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int r = threadIdx.x & 15;
+    const long long total = (long long)nc * P.B;
+    const long long it = item < total ? item : total - 1;
+    const long long b = it % P.B;
+    const int k = (int)(it / P.B);
+    const double step = P.ncand > 0 ? (double)exp2f(-(float)k) : 0.0;      // float steps, as the reference
+    const double *xu = P.xu + b * (long long)T * nt, *up = P.upd + b * (long long)T * nt;
+    const double *Qd = P.Qd + b * (long long)T * nt, *q = P.q + b * (long long)T * nt;
+    const double *lam = P.lam + b * (long long)ncon, *x0 = P.x0 + b * (long long)n;
+    const double rho = P.rho[b];
+    double acc = 0.0;
+    for (int t = r; t < T; t += 16) {
+        double z[16], zn[8], xn[8];
+        for (int j = 0; j < nt; ++j) z[j] = xu[t * nt + j] + step * up[t * nt + j];
+        if (t == 0) for (int j = 0; j < n; ++j) z[j] = x0[j];
+        for (int j = 0; j < nt; ++j) acc += (0.5 * Qd[t * nt + j] * z[j] + q[t * nt + j]) * z[j];
+        if (t < T - 1) {
+            switch (P.dyn) {
+            case DQP_DYN_PENDULUM1L: step_knot<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>(z, z + n, P.dt, xn); break;
+            case DQP_DYN_CARTPOLE1L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(z, z + n, P.dt, xn); break;
+            case DQP_DYN_CARTPOLE2L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(z, z + n, P.dt, xn); break;
+            case DQP_DYN_PENDULUM_EULER: step_knot<dqp::dyn::PendulumEuler>(z, z + n, P.dt, xn); break;
+            default: step_knot<dqp::dyn::PendulumDx>(z, z + n, P.dt, xn); break;
+            }
+            for (int j = 0; j < n; ++j) {
+                zn[j] = xu[(t + 1) * nt + j] + step * up[(t + 1) * nt + j];
+                const double res = zn[j] - xn[j];
+                acc += (0.5 * rho * res + lam[t * n + j]) * res;
+            }
+        } else {
+            for (int j = 0; j < n; ++j) {
+                const double first = x0[j];                      // the pinned x_0
+                const double res = first - x0[j];
+                acc += (0.5 * rho * res + lam[(T - 1) * n + j]) * res;
+            }
+        }
+        for (int i = 0; i < m; ++i) {
+            const double u = z[n + i], hi = u - P.uu[i], lo = P.ul[i] - u;
+            const int row = neq + t * 2 * m + i;
+            acc += lam[row] * hi + lam[row + m] * lo + 0.5 * rho * (fmax(hi, 0.0) * fmax(hi, 0.0) + fmax(lo, 0.0) * fmax(lo, 0.0));
+        }
+    }
+    acc = dqp::r16::row_sum(acc);
+    if (r == 0 && item < total) P.merit[item] = acc;
+}
+
+struct SelP {
+    const double *merit, *upd, *x0;
+    double *xu, *merit_cur, *status;
+    int32_t *fail;
+    const int32_t *info;
+    int B, n, nz, ncand;
+};
+
+// argmin over the candidates, acceptance test and update of the iterate (al_utils.py:516-526):
+// one 64-thread block per problem
+__global__ __launch_bounds__(64) void al_select_kernel(SelP P)
+{
+    const long long b = blockIdx.x;
+    __shared__ double s_step;
+    __shared__ int s_take;
+    if (threadIdx.x == 0) {
+        double best = P.merit[b];
+        int arg = 0;
+        bool nan = best != best;
+        for (int k = 1; k < P.ncand && !nan; ++k) {        // torch.min: NaN wins, else the first minimum
+            const double v = P.merit[(long long)k * P.B + b];
+            if (v != v) { best = v; arg = k; nan = true; }
+            else if (v < best) { best = v; arg = k; }
+        }
+        const bool take = best < P.merit_cur[b];
+        P.merit_cur[b] = best;                              // new_merit regardless of acceptance
+        if (P.status) P.status[b] = take ? 1.0 : 0.0;
+        if (P.info && P.info[b] != 0) atomicOr(P.fail, 1);  // Cholesky failed: the caller re-runs the slow path
+        s_step = (double)exp2f(-(float)arg);
+        s_take = take ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_take) return;
+    double *xu = P.xu + b * (long long)P.nz;
+    const double *up = P.upd + b * (long long)P.nz;
+    for (int e = threadIdx.x; e < P.nz; e += 64)
+        xu[e] = e < P.n ? P.x0[b * P.n + e] : xu[e] + s_step * up[e];
 }
 
 template <typename K>
@@ -587,7 +770,7 @@ dqp_al_assemble(const dqp_al_mpc_dims *d, const double *Jx, const double *Ju, co
     if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2) return DQP_ERR_BAD_ARG;
     if (d->nbatch == 0) return DQP_OK;
     if (!Jx || !Ju || !res_c || (gterm && (!lam || !rho))) return DQP_ERR_BAD_ARG;
-    AsmP P = {Jx, Ju, lam, res_c, rho, Jc, gterm, d->nbatch, d->n_state, d->n_ctrl, d->T};
+    AsmP P = {Jx, Ju, lam, res_c, rho, Jc, gterm, d->nbatch, d->n_state, d->n_ctrl, d->T, nullptr, nullptr, nullptr};
     hipLaunchKernelGGL(al_assemble_kernel, dim3(P.B), dim3(256), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
@@ -605,6 +788,80 @@ dqp_al_merit(const dqp_al_mpc_dims *d, int32_t ncand, const double *xu, const do
                 d->n_ctrl, d->T, ncand};
     const long long total = (long long)ncand * d->nbatch;
     hipLaunchKernelGGL(al_merit_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+
+// workspace of dqp_al_newton_solve, in doubles per problem (see the carve below)
+static size_t al_solve_doubles(int n, int m, int T)
+{
+    const size_t nt = n + m, nz = (size_t)T * nt, ncon = (size_t)T * n + 2 * (size_t)T * m;
+    return (size_t)(T - 1) * n * n + (size_t)(T - 1) * n * m + ncon + ncon * nz + nz + nz + 20 + 1 + 1;
+}
+
+__attribute__((visibility("default"))) size_t dqp_al_newton_solve_bytes(const dqp_al_mpc_dims *d)
+{
+    if (!d || d->nbatch <= 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2) return 0;
+    return ((size_t)d->nbatch * al_solve_doubles(d->n_state, d->n_ctrl, d->T) + 2) * sizeof(double);
+}
+
+__attribute__((visibility("default"))) int
+dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_steps, const double *x0,
+                    const double *Qdiag, const double *q, const double *lam, const double *rho,
+                    const double *u_lower, const double *u_upper, double *xu, double *L, double *status,
+                    int32_t *fail, void *workspace, void *stream)
+{
+    if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2 || n_steps < 1) return DQP_ERR_BAD_ARG;
+    if (d->nbatch == 0) return DQP_OK;
+    int32_t dn = 0, dm = 0;
+    if (dqp_dyn_sizes(dyn_id, &dn, &dm) != DQP_OK || dn != d->n_state || dm != d->n_ctrl) return DQP_ERR_BAD_ARG;
+    if (d->n_state > 8 || d->n_ctrl > 2) return DQP_ERR_TOO_LARGE;
+    if (!x0 || !Qdiag || !q || !lam || !rho || !u_lower || !u_upper || !xu || !fail || !workspace) return DQP_ERR_BAD_ARG;
+    const int B = d->nbatch, n = d->n_state, m = d->n_ctrl, T = d->T, nt = n + m, nz = T * nt;
+    const int ncon = T * n + 2 * T * m;
+    dqp_al_dims ad = {B, nz, ncon, 0};
+    AlP A = {};
+    size_t lds = 0;
+    int rc = fill(&ad, A, lds);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // carve
+    double *w = (double *)workspace;
+    double *Jx = w;            w += (size_t)B * (T - 1) * n * n;
+    double *Ju = w;            w += (size_t)B * (T - 1) * n * m;
+    double *resc = w;          w += (size_t)B * ncon;
+    double *Jc = w;            w += (size_t)B * ncon * nz;
+    double *grad = w;          w += (size_t)B * nz;
+    double *upd = w;           w += (size_t)B * nz;
+    double *merit = w;         w += (size_t)20 * B;
+    double *merit_cur = w;     w += (size_t)B;
+    int32_t *info = (int32_t *)w;
+    if (hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
+    LsAP Lp = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit_cur, dt, B, n, m, T, 0, dyn_id};
+    hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, Lp);   // merit at the start
+    for (int it = 0; it < n_steps; ++it) {
+        LinP Li = {xu, x0, u_lower, u_upper, Jx, Ju, resc, dt, B, n, m, T, dyn_id};
+        hipLaunchKernelGGL(al_linearize_kernel, dim3((unsigned)(((long long)B * T + 255) / 256)), dim3(256), 0, st, Li);
+        AsmP As = {Jx, Ju, lam, resc, rho, Jc, grad, B, n, m, T, Qdiag, q, xu};
+        hipLaunchKernelGGL(al_assemble_kernel, dim3(B), dim3(256), 0, st, As);
+        AlP P = A;
+        P.Jc = Jc; P.Qd = Qdiag; P.rho = rho; P.grad = grad; P.update = upd; P.L = L; P.info = info;
+        switch ((nz + 15) / 16) {
+        case 1: rc = launch(al_newton_kernel<1>, P, lds, stream); break;
+        case 2: rc = launch(al_newton_kernel<2>, P, lds, stream); break;
+        case 3: rc = launch(al_newton_kernel<3>, P, lds, stream); break;
+        case 4: rc = launch(al_newton_kernel<4>, P, lds, stream); break;
+        case 5: rc = launch(al_newton_kernel<5>, P, lds, stream); break;
+        case 6: rc = launch(al_newton_kernel<6>, P, lds, stream); break;
+        case 7: rc = launch(al_newton_kernel<7>, P, lds, stream); break;
+        default: rc = launch(al_newton_kernel<8>, P, lds, stream); break;
+        }
+        if (rc) return rc;
+        LsAP Lc = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, dt, B, n, m, T, 20, dyn_id};
+        hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)(((long long)20 * B + 15) / 16)), dim3(256), 0, st, Lc);
+        SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
+        hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
+    }
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 

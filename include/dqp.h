@@ -315,6 +315,26 @@ int dqp_al_merit(const dqp_al_mpc_dims *dims, int32_t ncand, const double *xu, c
                  const double *rho, const double *u_lower, const double *u_upper, double *merit,
                  void *stream);
 
+/*
+ * NewtonAL.forward for a registered device model (qpth/al_utils.py:363-456 with
+ * merit_grad_hessian :62-102, constraint_res_jac2 :162-318 and line_search_newton :503-527):
+ * n_steps Newton steps on the augmented Lagrangian, each = linearise the dynamics along xu
+ * (forward-mode Jacobians) -> clamped constraint Jacobian + merit gradient -> Hessian (fp64 MFMA) +
+ * Cholesky + solve -> merit of the 20 candidate steps 2^-k (dynamics evaluated in the kernel) ->
+ * argmin / acceptance / update.  5 launches per step, nothing returns to the host in between.
+ * xu (B,T,n+m) in/out; x0 (B,n); Qdiag, q (B,T,n+m); lam (B,ncon), rho (B); u_lower/u_upper (m).
+ * Outputs: L (B,nz,nz) the Cholesky factor of the LAST step's Hessian (what NewtonAL.backward
+ * needs, al_utils.py:458,477-480), status (B) 1.0 where the last line search accepted its step,
+ * fail (one int32) != 0 when a Cholesky factorisation broke down (the reference then switches the
+ * whole batch to an LU solve, al_utils.py:419-427: the caller re-runs its general path).
+ * n_state <= 8, n_ctrl <= 2, nz <= 128.
+ */
+size_t dqp_al_newton_solve_bytes(const dqp_al_mpc_dims *dims);
+int dqp_al_newton_solve(const dqp_al_mpc_dims *dims, int dyn_id, double dt, int32_t n_steps, const double *x0,
+                        const double *Qdiag, const double *q, const double *lam, const double *rho,
+                        const double *u_lower, const double *u_upper, double *xu, double *L, double *status,
+                        int32_t *fail, void *workspace, void *stream);
+
 /* ----------------------------------------------------------------- device dynamics registry */
 
 /*

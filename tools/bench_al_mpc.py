@@ -37,6 +37,11 @@ lim = torch.full((nu,), 2.0, dtype=torch.float64).cuda()
 ctrl = AL_mpc.MPC(nx, nu, T, u_lower=-lim, u_upper=lim, n_batch=B, verbose=0, solver_type="dense",
                   dtype=torch.float64, eps=1e-5, exit_unconverged=False, backprop=False)
 dyn, dyn_jac = Pendulum(), PendulumJac()
+if os.environ.get("DEVICE_DYN", "1") == "1":       # registered device model: fused NewtonAL path
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    dyn = DeviceDynamics("pendulum_euler")
+    dyn_jac = dyn.jac
+    AL_mpc.FUSED_NEWTON_AL = os.environ.get("FUSED", "1") == "1"
 def step():
     ctrl.reinitialize(x0, torch.ones(B, T, 1, device="cuda"))
     x, u = ctrl(x0, al_utils.QuadCost(C, c), dyn, dyn_jac)
