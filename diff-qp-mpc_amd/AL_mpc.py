@@ -19,6 +19,10 @@ from .dynamics import DeviceDynamics
 
 # registered device models run NewtonAL's four Newton steps as one C-ABI call (no Python in between)
 FUSED_NEWTON_AL = True
+# one host synchronisation per al_solve to look at the Cholesky-failure flags of the device path
+# (False: never look -- needed to capture a call in a hipGraph; a failed factorisation then leaves its
+# problem at the last accepted iterate)
+CHECK_CHOLESKY = True
 
 
 def _detach(t):
@@ -92,8 +96,13 @@ class MPC(Module):
         return (x, u)
 
     # ------------------------------------------------------------------ AL_mpc.py:254-321
-    def al_solve(self, x, u, dx, dx_jac, x0, cost, lamda_init=None, rho_init=None):
+    def al_solve(self, x, u, dx, dx_jac, x0, cost, lamda_init=None, rho_init=None, _fused=True):
         dt = self.dtype
+        x_in, u_in, x0_in = x, u, x0
+        device_path = (_fused and FUSED_NEWTON_AL and isinstance(dx, DeviceDynamics) and self.n_state <= 8
+                       and self.n_ctrl <= 2 and self.x_lower is None and self.u_lower.numel() == self.n_ctrl
+                       and (al_utils.BANDED_NEWTON_AL or self.T * (self.n_state + self.n_ctrl) <= 128))
+        fail_flags = []
         x, u, x0 = x.to(dt), u.to(dt), x0.to(dt)
         lamda = self.lamda_prev.to(dt) if lamda_init is None else lamda_init
         rho = self.rho_prev if rho_init is None else rho_init
@@ -116,25 +125,32 @@ class MPC(Module):
                     lambda xi, Qi, qi: self.compute_cost(xi, Qi, qi),
                     lambda xi, Qi, qi, yi: self.merit_grad_hess(xi, Qi, qi, dx, dx_jac, x0, yi, rho_i),
                     xu, x0, lamda, rho, Qg, qg, 1e-3, 1e-6, True)
-            if (FUSED_NEWTON_AL and isinstance(dx, DeviceDynamics) and self.n_state <= 8 and self.n_ctrl <= 2
-                    and self.T * (self.n_state + self.n_ctrl) <= 128 and self.x_lower is None
-                    and self.u_lower.numel() == self.n_ctrl and torch.is_tensor(rho)):
-                # registered device model: the four Newton steps in one C-ABI call (dqp_al_newton_solve)
+            if device_path and torch.is_tensor(rho):
+                # registered device model: the four Newton steps in one C-ABI call (dqp_al_newton_solve);
+                # Cholesky-failure flags are collected and checked once after the last AL iteration
                 out, status = al_utils.NewtonALDevice.apply(xu, x0, lamda, rho, Q, q, dx, self.u_lower,
-                                                            self.u_upper, general)
+                                                            self.u_upper, general, fail_flags)
             else:
                 out, status = general(Q, q)
             x, u = out[:, :, :self.n_state], out[:, :, self.n_state:]
             with torch.no_grad():
-                res, res_clamp = self.dyn_res(torch.cat((x, u), dim=2), dx, x0, res_type='both')
-                lamda = lamda + rho * res                                 # AL_mpc.py:299
-                lamda = torch.cat([lamda[:, :self.neq], lamda[:, self.neq:].clamp(min=0)], dim=1)
-                cost_res = self.compute_cost(out, Q, q)
-                dyn_res_clamp = res_clamp.view(self.n_batch, -1).norm(dim=-1)
+                if device_path and torch.is_tensor(rho):
+                    lamda, cost_res, dyn_res_clamp = al_utils.outer_update_device(
+                        out, x0, lamda, rho, Q, q, dx, self.u_lower, self.u_upper)
+                else:
+                    res, res_clamp = self.dyn_res(torch.cat((x, u), dim=2), dx, x0, res_type='both')
+                    lamda = lamda + rho * res                                 # AL_mpc.py:299
+                    lamda = torch.cat([lamda[:, :self.neq], lamda[:, self.neq:].clamp(min=0)], dim=1)
+                    cost_res = self.compute_cost(out, Q, q)
+                    dyn_res_clamp = res_clamp.view(self.n_batch, -1).norm(dim=-1)
                 rho = rho * 10                                             # AL_mpc.py:307
                 history[0].append(cost_res)
                 history[1].append(lamda)
                 history[2].append(rho)
+        if fail_flags and CHECK_CHOLESKY and bool(torch.stack(fail_flags).any()):
+            # a Cholesky factorisation broke down somewhere in the batch: the reference then switches
+            # the batch to an LU solve (al_utils.py:419-427) -- redo this solve on the general path
+            return self.al_solve(x_in, u_in, dx, dx_jac, x0_in, cost, lamda_init, rho_init, _fused=False)
         self.cost_lam_hist = history
         self.lamda_prev, self.rho_prev, self.dyn_res_prev = lamda, rho, dyn_res_clamp
         self.just_initialized = False
@@ -158,6 +174,11 @@ class MPC(Module):
         return res, res_clamp
 
     def rollout(self, x, actions, dynamics):
+        if isinstance(dynamics, DeviceDynamics) and x.is_cuda and self.n_state <= 8 and self.n_ctrl <= 8:
+            # one launch (and one for its adjoint) instead of T-1 dynamics calls
+            from .qp_wrapper import _Rollout
+            xs = _Rollout.apply(x, actions.transpose(0, 1), None, None, dynamics, self.n_state, self.n_ctrl, self.T)
+            return xs.transpose(0, 1)
         xs = [x]
         for t in range(self.T - 1):
             xt, ut = xs[t], actions[:, t]

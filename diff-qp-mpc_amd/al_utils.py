@@ -31,6 +31,9 @@ LinDx = namedtuple("LinDx", "F f")
 QuadCost.__new__.__defaults__ = (None,) * len(QuadCost._fields)
 LinDx.__new__.__defaults__ = (None,) * len(LinDx._fields)
 
+# NewtonALDevice: True = the block-tridiagonal Newton step (one launch, no Jacobian / Hessian in HBM),
+# False = dense Jacobian + MFMA Hessian + dense Cholesky (the reference's own formulation)
+BANDED_NEWTON_AL = True
 N_LINESEARCH = 20          # al_utils.py:504
 MAX_NEWTON_STEPS = 4       # al_utils.py:391
 
@@ -349,7 +352,7 @@ class NewtonALDevice(torch.autograd.Function):
     LU solve (al_utils.py:419-427)."""
 
     @staticmethod
-    def forward(ctx, xi, x0, lam, rho, Q, q, dyn, u_lower, u_upper, slow):
+    def forward(ctx, xi, x0, lam, rho, Q, q, dyn, u_lower, u_upper, slow, fail_sink=None):
         lib = _lib.load()
         B, T, nt = xi.shape
         n, m = dyn.n_state, dyn.n_ctrl
@@ -359,21 +362,29 @@ class NewtonALDevice(torch.autograd.Function):
         keep = [d64(x0), d64(Q), d64(q), d64(lam), d64(rho).reshape(B), d64(u_lower).reshape(-1), d64(u_upper).reshape(-1)]
         dims = _lib.dqp_al_mpc_dims(B, n, m, T)
         kw = dict(dtype=torch.float64, device=dev)
-        L = torch.empty(B, T * nt, T * nt, **kw)
+        banded = 1 if BANDED_NEWTON_AL else 0
+        if banded:      # block-tridiagonal factor, per knot (dqp_al_banded.hip)
+            L = torch.empty(int(lib.dqp_al_banded_factor_bytes(ctypes.byref(dims), dyn.id)) // 8, **kw)
+        else:
+            L = torch.empty(B, T * nt, T * nt, **kw)
         status = torch.empty(B, **kw)
         fail = torch.zeros(1, dtype=torch.int32, device=dev)
         ws = torch.empty(int(lib.dqp_al_newton_solve_bytes(ctypes.byref(dims))) // 8 + 1, **kw)
         with torch.cuda.device(dev):
-            rc = lib.dqp_al_newton_solve(ctypes.byref(dims), dyn.id, dyn.dt, MAX_NEWTON_STEPS, *[_ptr(t) for t in keep],
-                                         _ptr(xu), _ptr(L), _ptr(status), _ptr(fail), _ptr(ws), _stream(dev))
+            rc = lib.dqp_al_newton_solve(ctypes.byref(dims), dyn.id, dyn.dt, MAX_NEWTON_STEPS, banded,
+                                         *[_ptr(t) for t in keep], _ptr(xu), _ptr(L), _ptr(status), _ptr(fail),
+                                         _ptr(ws), _stream(dev))
         _lib.check(rc, "dqp_al_newton_solve")
         ctx.slow_ctx = None
-        if bool(fail.item()):               # rare: re-run through the general path, incl. its backward
+        if fail_sink is not None:           # the caller checks all flags once, at the end of its solve
+            fail_sink.append(fail)
+        elif bool(fail.item()):             # rare: re-run through the general path, incl. its backward
             with torch.enable_grad():
                 Qs, qs = Q.detach().requires_grad_(), q.detach().requires_grad_()
                 out, st = slow(Qs, qs)
             ctx.slow_ctx = (out, Qs, qs)
             return out.detach(), st.detach()
+        ctx.banded, ctx.dims, ctx.dyn_id = banded, dims, dyn.id
         ctx.save_for_backward(L, xu)
         return xu.to(xi.dtype), status.to(torch.float32)
 
@@ -382,10 +393,36 @@ class NewtonALDevice(torch.autograd.Function):
         if ctx.slow_ctx is not None:
             out, Qs, qs = ctx.slow_ctx
             gQ, gq = torch.autograd.grad(out, (Qs, qs), x_grad)
-            return (None,) * 4 + (gQ, gq) + (None,) * 4
+            return (None,) * 4 + (gQ, gq) + (None,) * 5
         L, x = ctx.saved_tensors
-        g = chol_solve_neg(L, x_grad).reshape(x_grad.shape).to(x_grad.dtype)
-        return (None,) * 4 + (g * x.to(x_grad.dtype), g) + (None,) * 4      # al_utils.py:482-485
+        if ctx.banded:
+            rhs = x_grad.detach().double().contiguous()
+            g = torch.empty_like(rhs)
+            with torch.cuda.device(rhs.device):
+                rc = _lib.load().dqp_al_banded_solve(ctypes.byref(ctx.dims), ctx.dyn_id, _ptr(L), _ptr(rhs), _ptr(g),
+                                                     _stream(rhs.device))
+            _lib.check(rc, "dqp_al_banded_solve")
+            g = g.to(x_grad.dtype)
+        else:
+            g = chol_solve_neg(L, x_grad).reshape(x_grad.shape).to(x_grad.dtype)
+        return (None,) * 4 + (g * x.to(x_grad.dtype), g) + (None,) * 5      # al_utils.py:482-485
+
+
+def outer_update_device(xu, x0, lam, rho, Q, q, dyn, u_lower, u_upper):
+    """AL_mpc.py:296-307 in one launch (dqp_al_outer_update): -> (lam_new, cost (B), |res_clamp| (B))."""
+    lib = _lib.load()
+    B, T, nt = xu.shape
+    dev = xu.device
+    d64 = lambda t: t.detach().double().contiguous()
+    keep = [d64(xu), d64(x0), d64(lam), d64(rho).reshape(B), d64(Q), d64(q), d64(u_lower).reshape(-1), d64(u_upper).reshape(-1)]
+    kw = dict(dtype=torch.float64, device=dev)
+    lam_new, cost, resn = torch.empty_like(keep[2]), torch.empty(B, **kw), torch.empty(B, **kw)
+    dims = _lib.dqp_al_mpc_dims(B, dyn.n_state, dyn.n_ctrl, T)
+    with torch.cuda.device(dev):
+        rc = lib.dqp_al_outer_update(ctypes.byref(dims), dyn.id, dyn.dt, *[_ptr(t) for t in keep], _ptr(lam_new),
+                                     _ptr(cost), _ptr(resn), _stream(dev))
+    _lib.check(rc, "dqp_al_outer_update")
+    return lam_new.to(lam.dtype), cost.to(xu.dtype), resn.to(xu.dtype)
 
 
 def warm_start_al(x, lamda, rho, cost_start, cost_hist, lam_hist, rho_hist):

@@ -672,6 +672,67 @@ __global__ __launch_bounds__(256) void al_ls_kernel(LsAP P)
     if (r == 0 && item < total) P.merit[item] = acc;
 }
 
+struct OutP {
+    const double *xu, *x0, *lam, *rho, *Qd, *q, *ul, *uu;
+    double *lam_new, *cost, *resn;
+    double dt;
+    int B, n, m, T, dyn;
+};
+
+// Between two AL iterations (qpth/AL_mpc.py:296-307): res = constraint residual at the new iterate,
+// lam <- lam + rho res with the inequality block clamped at 0, cost of the iterate and the norm of
+// the clamped residual; 16 lanes per problem, dynamics evaluated in the kernel.
+__global__ __launch_bounds__(256) void al_outer_kernel(OutP P)
+{
+    const int n = P.n, m = P.m, T = P.T, nt = n + m, neq = T * n, ncon = neq + 2 * T * m;
+    const long long item = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int r = threadIdx.x & 15;
+    const long long b = item < P.B ? item : P.B - 1;
+    const bool live = item < P.B;
+    const double *xu = P.xu + b * (long long)T * nt, *lam = P.lam + b * (long long)ncon;
+    const double *Qd = P.Qd + b * (long long)T * nt, *q = P.q + b * (long long)T * nt;
+    double *ln = P.lam_new + b * (long long)ncon;
+    const double rho = P.rho[b];
+    double cost = 0.0, rn2 = 0.0;
+    for (int t = r; t < T; t += 16) {
+        double z[16], xn[8];
+        for (int j = 0; j < nt; ++j) z[j] = xu[t * nt + j];
+        for (int j = 0; j < nt; ++j) cost += (0.5 * Qd[t * nt + j] * z[j] + q[t * nt + j]) * z[j];
+        if (t < T - 1) {
+            switch (P.dyn) {
+            case DQP_DYN_PENDULUM1L: step_knot<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>(z, z + n, P.dt, xn); break;
+            case DQP_DYN_CARTPOLE1L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(z, z + n, P.dt, xn); break;
+            case DQP_DYN_CARTPOLE2L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(z, z + n, P.dt, xn); break;
+            case DQP_DYN_PENDULUM_EULER: step_knot<dqp::dyn::PendulumEuler>(z, z + n, P.dt, xn); break;
+            default: step_knot<dqp::dyn::PendulumDx>(z, z + n, P.dt, xn); break;
+            }
+            for (int j = 0; j < n; ++j) {
+                const double res = xu[(t + 1) * nt + j] - xn[j];
+                rn2 += res * res;
+                if (live) ln[t * n + j] = lam[t * n + j] + rho * res;
+            }
+        } else {
+            for (int j = 0; j < n; ++j) {
+                const double res = xu[j] - P.x0[b * n + j];
+                rn2 += res * res;
+                if (live) ln[(T - 1) * n + j] = lam[(T - 1) * n + j] + rho * res;
+            }
+        }
+        for (int i = 0; i < m; ++i) {
+            const double u = z[n + i], hi = u - P.uu[i], lo = P.ul[i] - u;
+            const int row = neq + t * 2 * m + i;
+            rn2 += fmax(hi, 0.0) * fmax(hi, 0.0) + fmax(lo, 0.0) * fmax(lo, 0.0);
+            if (live) {
+                ln[row] = fmax(lam[row] + rho * hi, 0.0);               // AL_mpc.py:300-301
+                ln[row + m] = fmax(lam[row + m] + rho * lo, 0.0);
+            }
+        }
+    }
+    cost = dqp::r16::row_sum(cost);
+    rn2 = dqp::r16::row_sum(rn2);
+    if (live && r == 0) { P.cost[b] = cost; P.resn[b] = sqrt(rn2); }
+}
+
 struct SelP {
     const double *merit, *upd, *x0;
     double *xu, *merit_cur, *status;
@@ -806,8 +867,8 @@ __attribute__((visibility("default"))) size_t dqp_al_newton_solve_bytes(const dq
 }
 
 __attribute__((visibility("default"))) int
-dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_steps, const double *x0,
-                    const double *Qdiag, const double *q, const double *lam, const double *rho,
+dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_steps, int32_t banded,
+                    const double *x0, const double *Qdiag, const double *q, const double *lam, const double *rho,
                     const double *u_lower, const double *u_upper, double *xu, double *L, double *status,
                     int32_t *fail, void *workspace, void *stream)
 {
@@ -839,6 +900,21 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
     if (hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
     LsAP Lp = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit_cur, dt, B, n, m, T, 0, dyn_id};
     hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, Lp);   // merit at the start
+    if (banded) {
+        // block-tridiagonal form (dqp_al_banded.hip): linearise + gradient + block Cholesky + solve in
+        // ONE launch per step, no Jacobian / Hessian in HBM; L receives the banded factor
+        if (!L) return DQP_ERR_BAD_ARG;
+        for (int it = 0; it < n_steps; ++it) {
+            rc = dqp_al_banded_newton_step(d, dyn_id, dt, xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, upd, L,
+                                           info, stream);
+            if (rc) return rc;
+            LsAP Lc = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, dt, B, n, m, T, 20, dyn_id};
+            hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)(((long long)20 * B + 15) / 16)), dim3(256), 0, st, Lc);
+            SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
+            hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
+        }
+        return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+    }
     for (int it = 0; it < n_steps; ++it) {
         LinP Li = {xu, x0, u_lower, u_upper, Jx, Ju, resc, dt, B, n, m, T, dyn_id};
         hipLaunchKernelGGL(al_linearize_kernel, dim3((unsigned)(((long long)B * T + 255) / 256)), dim3(256), 0, st, Li);
@@ -862,6 +938,26 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
         SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
         hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
     }
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+
+__attribute__((visibility("default"))) int
+dqp_al_outer_update(const dqp_al_mpc_dims *d, int dyn_id, double dt, const double *xu, const double *x0,
+                    const double *lam, const double *rho, const double *Qdiag, const double *q,
+                    const double *u_lower, const double *u_upper, double *lam_new, double *cost,
+                    double *res_norm, void *stream)
+{
+    if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2) return DQP_ERR_BAD_ARG;
+    if (d->nbatch == 0) return DQP_OK;
+    int32_t dn = 0, dm = 0;
+    if (dqp_dyn_sizes(dyn_id, &dn, &dm) != DQP_OK || dn != d->n_state || dm != d->n_ctrl) return DQP_ERR_BAD_ARG;
+    if (d->n_state > 8 || d->n_state + d->n_ctrl > 16) return DQP_ERR_TOO_LARGE;
+    if (!xu || !x0 || !lam || !rho || !Qdiag || !q || !u_lower || !u_upper || !lam_new || !cost || !res_norm)
+        return DQP_ERR_BAD_ARG;
+    OutP P = {xu, x0, lam, rho, Qdiag, q, u_lower, u_upper, lam_new, cost, res_norm, dt, d->nbatch, d->n_state,
+              d->n_ctrl, d->T, dyn_id};
+    hipLaunchKernelGGL(al_outer_kernel, dim3((unsigned)((P.B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 

@@ -1,0 +1,346 @@
+// dqp_al_banded.hip -- NewtonAL for registered device models with the MPC structure exploited.
+//
+// The augmented-Lagrangian Hessian of the reference (qpth/al_utils.py:62-102: diag(Q) + rho Jc^T Jc
+// with Jc the clamped constraint Jacobian of al_utils.py:162-318) is block tridiagonal in the
+// knots: a dynamics row block couples knot t and t+1 only, box rows touch one control.  The
+// reference builds the dense (B, ncon, nz) Jacobian, a dense bmm and a dense Cholesky
+// (O(nz^3), nz = T (n+m)); here one launch per Newton step does, per problem,
+//
+//   forward sweep over the knots t = 0 .. T-1  (everything of a knot lives in registers):
+//     J_t = [df/dx, df/du](x_t, u_t)      lane i evaluates the model with ONE forward-mode seed e_i
+//                                         -> column i of J_t: 16 lanes = all columns at once
+//     g_t  = Q z + q + J^T (lam + rho res_c)                             (merit gradient rows)
+//     H_tt = diag(Q) + rho (J_t^T J_t + I_x + active box indicators),  H_{t+1,t} = -rho E_x^T J_t
+//     S_t  = H_tt - L_{t,t-1} L_{t,t-1}^T ;  L_tt = chol(S_t) ;  L_{t+1,t}^T = L_tt^-1 H_{t+1,t}^T
+//     y_t  = L_tt^-1 (-g_t - L_{t,t-1} y_{t-1})
+//   backward sweep t = T-1 .. 0:   upd_t = L_tt^-T (y_t - L_{t+1,t}^T upd_{t+1})
+//
+// i.e. the block Cholesky of the same matrix: O(T (n+m)^3) instead of O(T^3 (n+m)^3), no Jacobian or
+// Hessian in HBM.  One problem per 16-lane DPP row (4 per wavefront), matrices row-distributed over
+// the lanes as in the QP kernels (dqp_r16_prims.h).  The factor is kept in its banded form
+// (per knot: L_tt rows, 1/diag, L_{t+1,t}^T rows) for the backward pass (al_utils.py:477-480).
+//
+// HBM per Newton step and problem: xu, Qd, q (3 nz) + lam (ncon) in, update (nz) + banded factor
+// (T (nt^2 + nt n + nt)) out -- e.g. 6.6 KB at cartpole T = 20 against 177 KB for the dense path
+// (Jc written + read, L written).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/dqp.h"
+#include "dqp_r16_prims.h"
+#include "dqp_dyn_models.h"
+
+namespace {
+
+using namespace dqp::r16;
+using dqp::dyn::Dual;
+
+struct BandP {
+    const double *xu, *x0, *Qd, *q, *lam, *rho, *ul, *uu;    // forward inputs
+    const double *rhs;                                       // solve-only mode: right-hand side (B, nz)
+    double *upd;        // (B, T, nt): -H^-1 grad  (or -H^-1 rhs in solve-only mode)
+    double *fac;        // banded factor, per (b, t): nt rows x (nt + 1 + nx) doubles
+    int32_t *info;      // (B): 0 or 1 + knot of the first non-positive pivot
+    double dt;
+    int B, T;
+};
+
+template <class Map> struct BandCfg {
+    static constexpr int NX = Map::NX, NU = Map::NU, NT = NX + NU;
+    static constexpr int ROW = NT + 1 + NX;                  // per lane and knot: L row, 1/diag, M row
+    static_assert(NT <= 16, "one knot must fit a 16-lane DPP row");
+};
+
+// b <- L^-T b for a row-distributed lower-triangular NT x NT matrix in registers
+template <int NT>
+__device__ __forceinline__ void trsvT_rows(const double (&L)[1][NT], const double (&rd)[1], double (&b)[1], int r)
+{
+#pragma unroll
+    for (int j = NT - 1; j >= 0; --j) {
+        const double part = (r > j && r < NT) ? L[0][j] * b[0] : 0.0;
+        const double tot = row_sum(part);
+        if (r == j) b[0] = (b[0] - tot) * rd[0];
+    }
+}
+
+template <class Map>
+__global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
+{
+    using C = BandCfg<Map>;
+    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    const int lane = threadIdx.x, r = lane & 15;
+    long long b = (long long)blockIdx.x * 4 + (lane >> 4);
+    const bool live = b < P.B;
+    if (!live) b = P.B - 1;
+    const int T = P.T, neq = T * NX;
+    const double *xu = P.xu + b * (long long)T * NT, *Qd = P.Qd + b * (long long)T * NT, *q = P.q + b * (long long)T * NT;
+    const double *lam = P.lam + b * (long long)(neq + 2 * T * NU), *x0 = P.x0 + b * NX;
+    const double rho = P.rho[b];
+    double *fac = P.fac + b * (long long)T * NT * C::ROW;
+    const bool inT = r < NT;
+
+    double Mprev[NX], yprev[1] = {0.0}, mu_prev[NX];
+    int bad = 0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) { Mprev[j] = 0.0; mu_prev[j] = 0.0; }
+
+    for (int t = 0; t < T; ++t) {
+        // ---- the knot and its successor's state (uniform loads)
+        double z[NT], xn1[NX];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) z[j] = xu[t * NT + j];
+        const bool dynrow = t < T - 1;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) xn1[j] = dynrow ? xu[(t + 1) * NT + j] : 0.0;
+        // ---- column r of J_t = [df/dx df/du] by one forward-mode seed per lane
+        double Jc[NX], mu[NX];
+        {
+            Dual<1> xs[NX], us[NU], out[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) { xs[j] = Dual<1>(z[j]); xs[j].d[0] = (r == j) ? 1.0 : 0.0; }
+#pragma unroll
+            for (int j = 0; j < NU; ++j) { us[j] = Dual<1>(z[NX + j]); us[j].d[0] = (r == NX + j) ? 1.0 : 0.0; }
+            Map::template step<Dual<1>>(xs, us, P.dt, out);
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                Jc[j] = (dynrow && inT) ? out[j].d[0] : 0.0;
+                const double res = dynrow ? xn1[j] - out[j].v : 0.0;                 // x_{t+1} - f(x_t, u_t)
+                mu[j] = dynrow ? lam[t * NX + j] + rho * res : 0.0;
+            }
+        }
+        // ---- gradient element r of this knot, and the diagonal terms of H_tt
+        double zr = 0.0, qdr = 0.0, qr = 0.0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+            if (r == j) { zr = z[j]; qdr = Qd[t * NT + j]; qr = q[t * NT + j]; }
+        double g = qdr * zr + qr, dg = qdr;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) g -= Jc[j] * mu[j];
+        if (r < NX) {
+            double inc = 0.0;                       // + I block of the previous dynamics rows / the x_0 rows
+#pragma unroll
+            for (int j = 0; j < NX; ++j)
+                if (r == j) inc = (t > 0) ? mu_prev[j] : lam[(T - 1) * NX + j] + rho * (z[j] - x0[j]);
+            g += inc;
+            dg += rho;
+        } else if (inT) {
+            const int i = r - NX;
+            double u = 0.0, hi = 0.0, lo = 0.0;
+#pragma unroll
+            for (int k = 0; k < NU; ++k)
+                if (i == k) { u = z[NX + k]; hi = P.uu[k]; lo = P.ul[k]; }
+            const double rup = u - hi, rlo = lo - u;
+            const int row = neq + t * 2 * NU + i;
+            g += (lam[row] + rho * fmax(rup, 0.0)) - (lam[row + NU] + rho * fmax(rlo, 0.0));
+            dg += rho * ((rup > 0.0 ? 1.0 : 0.0) + (rlo > 0.0 ? 1.0 : 0.0));
+        }
+        // ---- H_tt row r:  rho J^T J + diag - Gram(M_prev) on the x-x block
+        double H[1][NT], rd[1];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) a = fma(Jc[j], rb(Jc[j], c), a);
+            H[0][c] = rho * a + ((r == c) ? dg : 0.0);
+        }
+        if (t > 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    const double tot = row_sum(Mprev[i] * Mprev[j]);
+                    if (r == i) H[0][j] -= tot;
+                    if (r == j && i != j) H[0][i] -= tot;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) H[0][c] = inT ? H[0][c] : ((r == c) ? 1.0 : 0.0);
+        if (!chol_rows<1, NT>(H, rd, r) && bad == 0) bad = t + 1;
+        // ---- right-hand side: y_t = L_tt^-1 (-g_t - L_{t,t-1} y_{t-1})
+        double y[1] = {inT ? -g : 0.0};
+        if (t > 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const double tot = row_sum(Mprev[i] * yprev[0]);
+                if (r == i) y[0] -= tot;
+            }
+        }
+        trsv_rows<1, NT>(H, rd, y, r);
+        // ---- M_t = L_tt^-1 H_{t+1,t}^T: column j of it is the distributed vector -rho J[j][:]
+        double M[NX];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) {
+            double v[1] = {-rho * Jc[j]};
+            trsv_rows<1, NT>(H, rd, v, r);
+            M[j] = inT ? v[0] : 0.0;
+        }
+        // ---- keep the knot's factor rows (banded form) and y_t
+        if (live && inT) {
+            double *o = fac + ((long long)t * NT + r) * C::ROW;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) o[c] = H[0][c];
+            o[NT] = rd[0];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) o[NT + 1 + j] = M[j];
+        }
+        if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = y[0];        // y parked in the output
+#pragma unroll
+        for (int j = 0; j < NX; ++j) { Mprev[j] = M[j]; mu_prev[j] = mu[j]; }
+        yprev[0] = inT ? y[0] : 0.0;
+    }
+    // ---- backward sweep: upd_t = L_tt^-T (y_t - M_t upd_{t+1}[:NX])
+    double xnext[1] = {0.0};
+    for (int t = T - 1; t >= 0; --t) {
+        const double *o = fac + ((long long)t * NT + (inT ? r : 0)) * C::ROW;
+        double L[1][NT], rd[1], M[NX];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) L[0][c] = inT ? o[c] : 0.0;
+        rd[0] = inT ? o[NT] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) M[j] = inT ? o[NT + 1 + j] : 0.0;
+        double v[1] = {inT ? P.upd[b * (long long)T * NT + t * NT + (inT ? r : 0)] : 0.0};
+        if (t < T - 1) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) v[0] = fma(-M[j], rb(xnext[0], j), v[0]);
+        }
+        trsvT_rows<NT>(L, rd, v, r);
+        if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = v[0];
+        xnext[0] = inT ? v[0] : 0.0;
+    }
+    if (live && r == 0 && P.info) P.info[b] = bad;
+}
+
+// out = -(L L^T)^-1 rhs with the banded factor a forward launch left in `fac`
+// (NewtonAL.backward, al_utils.py:477-480)
+template <class Map>
+__global__ __launch_bounds__(64) void al_banded_solve_kernel(BandP P)
+{
+    using C = BandCfg<Map>;
+    constexpr int NX = C::NX, NT = C::NT;
+    const int lane = threadIdx.x, r = lane & 15;
+    long long b = (long long)blockIdx.x * 4 + (lane >> 4);
+    const bool live = b < P.B;
+    if (!live) b = P.B - 1;
+    const int T = P.T;
+    const bool inT = r < NT;
+    const double *fac = P.fac + b * (long long)T * NT * C::ROW;
+    double Mprev[NX], yprev = 0.0;
+#pragma unroll
+    for (int j = 0; j < NX; ++j) Mprev[j] = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double *o = fac + ((long long)t * NT + (inT ? r : 0)) * C::ROW;
+        double L[1][NT], rd[1], M[NX];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) L[0][c] = inT ? o[c] : ((r == c) ? 1.0 : 0.0);
+        rd[0] = inT ? o[NT] : 1.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) M[j] = inT ? o[NT + 1 + j] : 0.0;
+        double y[1] = {inT ? -P.rhs[b * (long long)T * NT + t * NT + (inT ? r : 0)] : 0.0};
+        if (t > 0) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const double tot = row_sum(Mprev[i] * yprev);
+                if (r == i) y[0] -= tot;
+            }
+        }
+        trsv_rows<1, NT>(L, rd, y, r);
+        if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = y[0];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) Mprev[j] = M[j];
+        yprev = inT ? y[0] : 0.0;
+    }
+    double xnext[1] = {0.0};
+    for (int t = T - 1; t >= 0; --t) {
+        const double *o = fac + ((long long)t * NT + (inT ? r : 0)) * C::ROW;
+        double L[1][NT], rd[1], M[NX];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) L[0][c] = inT ? o[c] : 0.0;
+        rd[0] = inT ? o[NT] : 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) M[j] = inT ? o[NT + 1 + j] : 0.0;
+        double v[1] = {inT ? P.upd[b * (long long)T * NT + t * NT + (inT ? r : 0)] : 0.0};
+        if (t < T - 1) {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) v[0] = fma(-M[j], rb(xnext[0], j), v[0]);
+        }
+        trsvT_rows<NT>(L, rd, v, r);
+        if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = v[0];
+        xnext[0] = inT ? v[0] : 0.0;
+    }
+}
+
+template <class Map> int run_newton(const BandP &P, void *stream)
+{
+    hipLaunchKernelGGL(al_banded_newton_kernel<Map>, dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+template <class Map> int run_solve(const BandP &P, void *stream)
+{
+    hipLaunchKernelGGL(al_banded_solve_kernel<Map>, dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+int knot_doubles(int id)          // nt rows x (L row, 1/diag, M row)
+{
+    int32_t n = 0, m = 0;
+    if (dqp_dyn_sizes(id, &n, &m) != DQP_OK) return 0;
+    return (n + m) * ((n + m) + 1 + n);
+}
+
+}  // namespace
+
+using namespace dqp::dyn;
+
+extern "C" {
+
+__attribute__((visibility("default"))) size_t dqp_al_banded_factor_bytes(const dqp_al_mpc_dims *d, int dyn_id)
+{
+    const int kd = knot_doubles(dyn_id);
+    if (!d || d->nbatch <= 0 || d->T < 2 || kd == 0) return 0;
+    return (size_t)d->nbatch * d->T * kd * sizeof(double);
+}
+
+__attribute__((visibility("default"))) int
+dqp_al_banded_newton_step(const dqp_al_mpc_dims *d, int dyn_id, double dt, const double *xu, const double *x0,
+                          const double *Qdiag, const double *q, const double *lam, const double *rho,
+                          const double *u_lower, const double *u_upper, double *update, void *factor,
+                          int32_t *info, void *stream)
+{
+    if (!d || d->nbatch < 0 || d->T < 2) return DQP_ERR_BAD_ARG;
+    int32_t n = 0, m = 0;
+    if (dqp_dyn_sizes(dyn_id, &n, &m) != DQP_OK || n != d->n_state || m != d->n_ctrl) return DQP_ERR_BAD_ARG;
+    if (d->nbatch == 0) return DQP_OK;
+    if (!xu || !x0 || !Qdiag || !q || !lam || !rho || !u_lower || !u_upper || !update || !factor) return DQP_ERR_BAD_ARG;
+    BandP P = {xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, nullptr, update, (double *)factor, info, dt, d->nbatch, d->T};
+    switch (dyn_id) {
+    case DQP_DYN_PENDULUM1L: return run_newton<Robot<Pendulum1l>>(P, stream);
+    case DQP_DYN_CARTPOLE1L: return run_newton<Robot<Cartpole1l>>(P, stream);
+    case DQP_DYN_CARTPOLE2L: return run_newton<Robot<Cartpole2l>>(P, stream);
+    case DQP_DYN_PENDULUM_EULER: return run_newton<PendulumEuler>(P, stream);
+    default: return run_newton<PendulumDx>(P, stream);
+    }
+}
+
+__attribute__((visibility("default"))) int
+dqp_al_banded_solve(const dqp_al_mpc_dims *d, int dyn_id, const void *factor, const double *rhs, double *out,
+                    void *stream)
+{
+    if (!d || d->nbatch < 0 || d->T < 2) return DQP_ERR_BAD_ARG;
+    int32_t n = 0, m = 0;
+    if (dqp_dyn_sizes(dyn_id, &n, &m) != DQP_OK || n != d->n_state || m != d->n_ctrl) return DQP_ERR_BAD_ARG;
+    if (d->nbatch == 0) return DQP_OK;
+    if (!factor || !rhs || !out) return DQP_ERR_BAD_ARG;
+    BandP P = {};
+    P.rhs = rhs; P.upd = out; P.fac = (double *)factor; P.B = d->nbatch; P.T = d->T;
+    switch (dyn_id) {
+    case DQP_DYN_PENDULUM1L: return run_solve<Robot<Pendulum1l>>(P, stream);
+    case DQP_DYN_CARTPOLE1L: return run_solve<Robot<Cartpole1l>>(P, stream);
+    case DQP_DYN_CARTPOLE2L: return run_solve<Robot<Cartpole2l>>(P, stream);
+    case DQP_DYN_PENDULUM_EULER: return run_solve<PendulumEuler>(P, stream);
+    default: return run_solve<PendulumDx>(P, stream);
+    }
+}
+
+}  // extern "C"

@@ -327,13 +327,41 @@ int dqp_al_merit(const dqp_al_mpc_dims *dims, int32_t ncand, const double *xu, c
  * needs, al_utils.py:458,477-480), status (B) 1.0 where the last line search accepted its step,
  * fail (one int32) != 0 when a Cholesky factorisation broke down (the reference then switches the
  * whole batch to an LU solve, al_utils.py:419-427: the caller re-runs its general path).
- * n_state <= 8, n_ctrl <= 2, nz <= 128.
+ * n_state <= 8, n_ctrl <= 2; nz <= 128 for the dense form (banded == 0), where L is (B,nz,nz);
+ * with banded != 0, L is the buffer of dqp_al_banded_factor_bytes (see below).
  */
 size_t dqp_al_newton_solve_bytes(const dqp_al_mpc_dims *dims);
-int dqp_al_newton_solve(const dqp_al_mpc_dims *dims, int dyn_id, double dt, int32_t n_steps, const double *x0,
-                        const double *Qdiag, const double *q, const double *lam, const double *rho,
-                        const double *u_lower, const double *u_upper, double *xu, double *L, double *status,
-                        int32_t *fail, void *workspace, void *stream);
+int dqp_al_newton_solve(const dqp_al_mpc_dims *dims, int dyn_id, double dt, int32_t n_steps, int32_t banded,
+                        const double *x0, const double *Qdiag, const double *q, const double *lam,
+                        const double *rho, const double *u_lower, const double *u_upper, double *xu, double *L,
+                        double *status, int32_t *fail, void *workspace, void *stream);
+
+/*
+ * Between two augmented-Lagrangian iterations (qpth/AL_mpc.py:296-307) for a registered device model:
+ * lam_new = lam + rho res with the inequality block clamped at 0, cost (B) of the iterate
+ * (diagonal cost), res_norm (B) = |clamped residual|; res in the row order of dqp_al_assemble.
+ */
+int dqp_al_outer_update(const dqp_al_mpc_dims *dims, int dyn_id, double dt, const double *xu, const double *x0,
+                        const double *lam, const double *rho, const double *Qdiag, const double *q,
+                        const double *u_lower, const double *u_upper, double *lam_new, double *cost,
+                        double *res_norm, void *stream);
+
+/*
+ * The same Newton step with the MPC structure exploited (`banded` != 0 above uses it): the Hessian
+ * diag(Q) + rho Jc^T Jc is block tridiagonal in the knots, so linearisation, gradient, block Cholesky
+ * and the solve run as ONE launch with every knot in registers (4 problems per wavefront), O(T (n+m)^3)
+ * work, no Jacobian or Hessian in HBM.  `factor` (dqp_al_banded_factor_bytes) receives the banded
+ * Cholesky factor -- per knot the rows of L_tt, 1/diag(L_tt) and L_{t+1,t}^T -- which
+ * dqp_al_banded_solve applies for NewtonAL.backward (out = -(L L^T)^-1 rhs, al_utils.py:477-480).
+ * info (B): 0, or 1 + the knot at which a pivot was not positive.
+ */
+size_t dqp_al_banded_factor_bytes(const dqp_al_mpc_dims *dims, int dyn_id);
+int dqp_al_banded_newton_step(const dqp_al_mpc_dims *dims, int dyn_id, double dt, const double *xu,
+                              const double *x0, const double *Qdiag, const double *q, const double *lam,
+                              const double *rho, const double *u_lower, const double *u_upper,
+                              double *update, void *factor, int32_t *info, void *stream);
+int dqp_al_banded_solve(const dqp_al_mpc_dims *dims, int dyn_id, const void *factor, const double *rhs,
+                        double *out, void *stream);
 
 /* ----------------------------------------------------------------- device dynamics registry */
 

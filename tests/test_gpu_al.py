@@ -309,3 +309,61 @@ def test_config3_full_size_properties():
     np.testing.assert_allclose(x[:4].cpu().numpy(), g["x1"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(u[:4].cpu().numpy(), g["u1"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(ctrl.lamda_prev[:4].cpu().numpy(), g["lam1"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("robot,T", [("pendulum_euler", 20), ("cartpole1l", 20), ("cartpole2l", 5), ("pendulum_dx", 10),
+                                     ("pendulum1l", 3)])
+def test_banded_newton_step_vs_dense_oracle(robot, T):
+    """dqp_al_banded_newton_step (block-tridiagonal Cholesky, every knot in registers) against the
+    reference's dense formulation restated in numpy (oracle/al_oracle.py: dense constraint Jacobian,
+    H = diag(Q) + rho Jc^T Jc, dense Cholesky solve) with the device model's own Jacobians: the same
+    matrix, factored in block form -> update rtol 1e-8 / atol 1e-10; and dqp_al_banded_solve against
+    the dense chol solve."""
+    import ctypes
+    from diff_qp_mpc_amd import _lib, al_utils
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    lib = _lib.load()
+    dyn = DeviceDynamics(robot)
+    n, m, nt = dyn.n_state, dyn.n_ctrl, dyn.n_state + dyn.n_ctrl
+    B = 37
+    gen = torch.Generator().manual_seed(T)
+    rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).cuda()
+    xu = 0.5 * rnd(B, T, nt)
+    if robot == "pendulum_dx":
+        xu[..., :2] = torch.nn.functional.normalize(xu[..., :2], dim=-1)
+    x0 = xu[:, 0, :n] + 0.1 * rnd(B, n)
+    Qd = torch.rand(B, T, nt, generator=gen, dtype=torch.float64).cuda() + 0.1
+    q = rnd(B, T, nt)
+    ncon = T * n + 2 * T * m
+    lam = rnd(B, ncon)
+    rho = (10.0 ** torch.randint(0, 3, (B, 1), generator=gen).double()).cuda()
+    lo, hi = torch.full((m,), -0.3, dtype=torch.float64).cuda(), torch.full((m,), 0.3, dtype=torch.float64).cuda()
+
+    def step_np(x, u):
+        xn, (Jx, Ju) = dyn.jac(dev(x), dev(u))
+        return xn.cpu().numpy(), Jx.cpu().numpy(), Ju.cpu().numpy()
+
+    res, resc, J, Jc = al_oracle.constraint_jacobian(xu.cpu().numpy(), x0.cpu().numpy(), lo.cpu().numpy(),
+                                                     hi.cpu().numpy(), step=step_np)
+    assert (resc[:, T * n:] > 0).any()
+    grad = al_oracle.merit_grad(xu.cpu().numpy(), Qd.cpu().numpy(), q.cpu().numpy(), lam.cpu().numpy(),
+                                rho.cpu().numpy(), resc, J, Jc)
+    upd_ref, L_ref, info_ref = al_oracle.newton_update(Jc, Qd.cpu().numpy().reshape(B, -1), rho.cpu().numpy(), grad)
+    assert not info_ref.any()
+    dims = _lib.dqp_al_mpc_dims(B, n, m, T)
+    fac = torch.empty(int(lib.dqp_al_banded_factor_bytes(ctypes.byref(dims), dyn.id)) // 8, dtype=torch.float64, device="cuda")
+    upd = torch.empty(B, T, nt, dtype=torch.float64, device="cuda")
+    info = torch.empty(B, dtype=torch.int32, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.dqp_al_banded_newton_step(ctypes.byref(dims), dyn.id, dyn.dt, P(xu), P(x0), P(Qd), P(q), P(lam),
+                                       P(rho.reshape(B).contiguous()), P(lo), P(hi), P(upd), P(fac), P(info), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(info.abs().max()) == 0
+    np.testing.assert_allclose(upd.cpu().numpy().reshape(B, -1), upd_ref, rtol=1e-8, atol=1e-10)
+    rhs = rnd(B, T, nt)
+    out = torch.empty_like(rhs)
+    assert lib.dqp_al_banded_solve(ctypes.byref(dims), dyn.id, P(fac), P(rhs), P(out), None) == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy().reshape(B, -1),
+                               al_oracle.chol_solve_neg(L_ref, rhs.cpu().numpy().reshape(B, -1)), rtol=1e-8, atol=1e-10)
