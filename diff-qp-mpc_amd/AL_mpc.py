@@ -99,9 +99,11 @@ class MPC(Module):
     def al_solve(self, x, u, dx, dx_jac, x0, cost, lamda_init=None, rho_init=None, _fused=True):
         dt = self.dtype
         x_in, u_in, x0_in = x, u, x0
-        device_path = (_fused and FUSED_NEWTON_AL and isinstance(dx, DeviceDynamics) and self.n_state <= 8
-                       and self.n_ctrl <= 2 and self.x_lower is None and self.u_lower.numel() == self.n_ctrl
-                       and (al_utils.BANDED_NEWTON_AL or self.T * (self.n_state + self.n_ctrl) <= 128))
+        nt = self.n_state + self.n_ctrl
+        banded = al_utils.BANDED_NEWTON_AL and nt <= 16                # one knot per 16-lane DPP row
+        dense = self.n_state <= 8 and self.n_ctrl <= 2 and self.T * nt <= 128
+        device_path = (_fused and FUSED_NEWTON_AL and isinstance(dx, DeviceDynamics) and (banded or dense)
+                       and self.x_lower is None and self.u_lower.numel() == self.n_ctrl)
         fail_flags = []
         x, u, x0 = x.to(dt), u.to(dt), x0.to(dt)
         lamda = self.lamda_prev.to(dt) if lamda_init is None else lamda_init
@@ -174,7 +176,7 @@ class MPC(Module):
         return res, res_clamp
 
     def rollout(self, x, actions, dynamics):
-        if isinstance(dynamics, DeviceDynamics) and x.is_cuda and self.n_state <= 8 and self.n_ctrl <= 8:
+        if isinstance(dynamics, DeviceDynamics) and x.is_cuda and self.n_state <= 12 and self.n_ctrl <= 8:
             # one launch (and one for its adjoint) instead of T-1 dynamics calls
             from .qp_wrapper import _Rollout
             xs = _Rollout.apply(x, actions.transpose(0, 1), None, None, dynamics, self.n_state, self.n_ctrl, self.T)

@@ -48,7 +48,8 @@ SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termin
            "dqp_al_outer_update", "dqp_al_banded_factor_bytes", "dqp_al_banded_newton_step", "dqp_al_banded_solve",
            "dqp_dyn_sizes", "dqp_dyn_step", "dqp_dyn_jacobian", "dqp_dyn_forward_dynamics",
            "dqp_dyn_forward_derivatives")
-DQP_DYN = {"pendulum1l": 1, "cartpole1l": 2, "cartpole2l": 3, "pendulum_euler": 4, "pendulum_dx": 5}
+DQP_DYN = {"pendulum1l": 1, "cartpole1l": 2, "cartpole2l": 3, "pendulum_euler": 4, "pendulum_dx": 5,
+           "rexquadrotor": 6}
 
 
 class dqp_al_mpc_dims(ctypes.Structure):
@@ -124,7 +125,7 @@ def load():
     lib.dqp_al_merit.restype = ctypes.c_int
     lib.dqp_al_merit.argtypes = [ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int32] + [_dp] * 11
     lib.dqp_al_newton_solve_bytes.restype = ctypes.c_size_t
-    lib.dqp_al_newton_solve_bytes.argtypes = [ctypes.POINTER(dqp_al_mpc_dims)]
+    lib.dqp_al_newton_solve_bytes.argtypes = [ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int32]
     lib.dqp_al_newton_solve.restype = ctypes.c_int
     lib.dqp_al_newton_solve.argtypes = ([ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int, ctypes.c_double, ctypes.c_int32,
                                          ctypes.c_int32] + [_dp] * 13)

@@ -369,7 +369,7 @@ class NewtonALDevice(torch.autograd.Function):
             L = torch.empty(B, T * nt, T * nt, **kw)
         status = torch.empty(B, **kw)
         fail = torch.zeros(1, dtype=torch.int32, device=dev)
-        ws = torch.empty(int(lib.dqp_al_newton_solve_bytes(ctypes.byref(dims))) // 8 + 1, **kw)
+        ws = torch.empty(int(lib.dqp_al_newton_solve_bytes(ctypes.byref(dims), banded)) // 8 + 1, **kw)
         with torch.cuda.device(dev):
             rc = lib.dqp_al_newton_solve(ctypes.byref(dims), dyn.id, dyn.dt, MAX_NEWTON_STEPS, banded,
                                          *[_ptr(t) for t in keep], _ptr(xu), _ptr(L), _ptr(status), _ptr(fail),

@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void al_ls_kernel(LsAP P)
     const double rho = P.rho[b];
     double acc = 0.0;
     for (int t = r; t < T; t += 16) {
-        double z[16], zn[8], xn[8];
+        double z[16], zn[12], xn[12];
         for (int j = 0; j < nt; ++j) z[j] = xu[t * nt + j] + step * up[t * nt + j];
         if (t == 0) for (int j = 0; j < n; ++j) z[j] = x0[j];
         for (int j = 0; j < nt; ++j) acc += (0.5 * Qd[t * nt + j] * z[j] + q[t * nt + j]) * z[j];
@@ -648,6 +648,7 @@ __global__ __launch_bounds__(256) void al_ls_kernel(LsAP P)
             case DQP_DYN_CARTPOLE1L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(z, z + n, P.dt, xn); break;
             case DQP_DYN_CARTPOLE2L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(z, z + n, P.dt, xn); break;
             case DQP_DYN_PENDULUM_EULER: step_knot<dqp::dyn::PendulumEuler>(z, z + n, P.dt, xn); break;
+            case DQP_DYN_REXQUADROTOR: step_knot<dqp::dyn::RexQuadrotor>(z, z + n, P.dt, xn); break;
             default: step_knot<dqp::dyn::PendulumDx>(z, z + n, P.dt, xn); break;
             }
             for (int j = 0; j < n; ++j) {
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(256) void al_outer_kernel(OutP P)
     const double rho = P.rho[b];
     double cost = 0.0, rn2 = 0.0;
     for (int t = r; t < T; t += 16) {
-        double z[16], xn[8];
+        double z[16], xn[12];
         for (int j = 0; j < nt; ++j) z[j] = xu[t * nt + j];
         for (int j = 0; j < nt; ++j) cost += (0.5 * Qd[t * nt + j] * z[j] + q[t * nt + j]) * z[j];
         if (t < T - 1) {
@@ -704,6 +705,7 @@ __global__ __launch_bounds__(256) void al_outer_kernel(OutP P)
             case DQP_DYN_CARTPOLE1L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(z, z + n, P.dt, xn); break;
             case DQP_DYN_CARTPOLE2L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(z, z + n, P.dt, xn); break;
             case DQP_DYN_PENDULUM_EULER: step_knot<dqp::dyn::PendulumEuler>(z, z + n, P.dt, xn); break;
+            case DQP_DYN_REXQUADROTOR: step_knot<dqp::dyn::RexQuadrotor>(z, z + n, P.dt, xn); break;
             default: step_knot<dqp::dyn::PendulumDx>(z, z + n, P.dt, xn); break;
             }
             for (int j = 0; j < n; ++j) {
@@ -860,9 +862,11 @@ static size_t al_solve_doubles(int n, int m, int T)
     return (size_t)(T - 1) * n * n + (size_t)(T - 1) * n * m + ncon + ncon * nz + nz + nz + 20 + 1 + 1;
 }
 
-__attribute__((visibility("default"))) size_t dqp_al_newton_solve_bytes(const dqp_al_mpc_dims *d)
+__attribute__((visibility("default"))) size_t dqp_al_newton_solve_bytes(const dqp_al_mpc_dims *d, int32_t banded)
 {
     if (!d || d->nbatch <= 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2) return 0;
+    if (banded)         // update + 20 candidate merits + current merit + info per problem
+        return ((size_t)d->nbatch * ((size_t)d->T * (d->n_state + d->n_ctrl) + 20 + 1 + 1) + 2) * sizeof(double);
     return ((size_t)d->nbatch * al_solve_doubles(d->n_state, d->n_ctrl, d->T) + 2) * sizeof(double);
 }
 
@@ -876,18 +880,40 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
     if (d->nbatch == 0) return DQP_OK;
     int32_t dn = 0, dm = 0;
     if (dqp_dyn_sizes(dyn_id, &dn, &dm) != DQP_OK || dn != d->n_state || dm != d->n_ctrl) return DQP_ERR_BAD_ARG;
-    if (d->n_state > 8 || d->n_ctrl > 2) return DQP_ERR_TOO_LARGE;
     if (!x0 || !Qdiag || !q || !lam || !rho || !u_lower || !u_upper || !xu || !fail || !workspace) return DQP_ERR_BAD_ARG;
     const int B = d->nbatch, n = d->n_state, m = d->n_ctrl, T = d->T, nt = n + m, nz = T * nt;
     const int ncon = T * n + 2 * T * m;
+    hipStream_t st = (hipStream_t)stream;
+    double *w = (double *)workspace;
+    if (banded) {
+        // block-tridiagonal form (dqp_al_banded.hip): linearise + gradient + block Cholesky + solve in
+        // ONE launch per step, no Jacobian / Hessian in HBM; L receives the banded factor
+        if (nt > 16 || n > 12) return DQP_ERR_TOO_LARGE;
+        if (!L) return DQP_ERR_BAD_ARG;
+        double *upd = w;           w += (size_t)B * nz;
+        double *merit = w;         w += (size_t)20 * B;
+        double *merit_cur = w;     w += (size_t)B;
+        int32_t *info = (int32_t *)w;
+        if (hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
+        LsAP Lp = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit_cur, dt, B, n, m, T, 0, dyn_id};
+        hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, Lp);   // merit at the start
+        for (int it = 0; it < n_steps; ++it) {
+            int rc = dqp_al_banded_newton_step(d, dyn_id, dt, xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, upd, L,
+                                               info, stream);
+            if (rc) return rc;
+            LsAP Lc = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, dt, B, n, m, T, 20, dyn_id};
+            hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)(((long long)20 * B + 15) / 16)), dim3(256), 0, st, Lc);
+            SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
+            hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
+        }
+        return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+    }
+    if (d->n_state > 8 || d->n_ctrl > 2) return DQP_ERR_TOO_LARGE;
     dqp_al_dims ad = {B, nz, ncon, 0};
     AlP A = {};
     size_t lds = 0;
     int rc = fill(&ad, A, lds);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    // carve
-    double *w = (double *)workspace;
     double *Jx = w;            w += (size_t)B * (T - 1) * n * n;
     double *Ju = w;            w += (size_t)B * (T - 1) * n * m;
     double *resc = w;          w += (size_t)B * ncon;
@@ -900,21 +926,6 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
     if (hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
     LsAP Lp = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit_cur, dt, B, n, m, T, 0, dyn_id};
     hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, Lp);   // merit at the start
-    if (banded) {
-        // block-tridiagonal form (dqp_al_banded.hip): linearise + gradient + block Cholesky + solve in
-        // ONE launch per step, no Jacobian / Hessian in HBM; L receives the banded factor
-        if (!L) return DQP_ERR_BAD_ARG;
-        for (int it = 0; it < n_steps; ++it) {
-            rc = dqp_al_banded_newton_step(d, dyn_id, dt, xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, upd, L,
-                                           info, stream);
-            if (rc) return rc;
-            LsAP Lc = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, dt, B, n, m, T, 20, dyn_id};
-            hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)(((long long)20 * B + 15) / 16)), dim3(256), 0, st, Lc);
-            SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
-            hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
-        }
-        return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
-    }
     for (int it = 0; it < n_steps; ++it) {
         LinP Li = {xu, x0, u_lower, u_upper, Jx, Ju, resc, dt, B, n, m, T, dyn_id};
         hipLaunchKernelGGL(al_linearize_kernel, dim3((unsigned)(((long long)B * T + 255) / 256)), dim3(256), 0, st, Li);
@@ -952,7 +963,7 @@ dqp_al_outer_update(const dqp_al_mpc_dims *d, int dyn_id, double dt, const doubl
     if (d->nbatch == 0) return DQP_OK;
     int32_t dn = 0, dm = 0;
     if (dqp_dyn_sizes(dyn_id, &dn, &dm) != DQP_OK || dn != d->n_state || dm != d->n_ctrl) return DQP_ERR_BAD_ARG;
-    if (d->n_state > 8 || d->n_state + d->n_ctrl > 16) return DQP_ERR_TOO_LARGE;
+    if (d->n_state > 12 || d->n_state + d->n_ctrl > 16) return DQP_ERR_TOO_LARGE;
     if (!xu || !x0 || !lam || !rho || !Qdiag || !q || !u_lower || !u_upper || !lam_new || !cost || !res_norm)
         return DQP_ERR_BAD_ARG;
     OutP P = {xu, x0, lam, rho, Qdiag, q, u_lower, u_upper, lam_new, cost, res_norm, dt, d->nbatch, d->n_state,

@@ -319,6 +319,7 @@ dqp_al_banded_newton_step(const dqp_al_mpc_dims *d, int dyn_id, double dt, const
     case DQP_DYN_CARTPOLE1L: return run_newton<Robot<Cartpole1l>>(P, stream);
     case DQP_DYN_CARTPOLE2L: return run_newton<Robot<Cartpole2l>>(P, stream);
     case DQP_DYN_PENDULUM_EULER: return run_newton<PendulumEuler>(P, stream);
+    case DQP_DYN_REXQUADROTOR: return run_newton<RexQuadrotor>(P, stream);
     default: return run_newton<PendulumDx>(P, stream);
     }
 }
@@ -339,6 +340,7 @@ dqp_al_banded_solve(const dqp_al_mpc_dims *d, int dyn_id, const void *factor, co
     case DQP_DYN_CARTPOLE1L: return run_solve<Robot<Cartpole1l>>(P, stream);
     case DQP_DYN_CARTPOLE2L: return run_solve<Robot<Cartpole2l>>(P, stream);
     case DQP_DYN_PENDULUM_EULER: return run_solve<PendulumEuler>(P, stream);
+    case DQP_DYN_REXQUADROTOR: return run_solve<RexQuadrotor>(P, stream);
     default: return run_solve<PendulumDx>(P, stream);
     }
 }

@@ -171,6 +171,7 @@ __attribute__((visibility("default"))) int dqp_dyn_sizes(int id, int32_t *n_stat
     case DQP_DYN_CARTPOLE2L: n = 6; break;
     case DQP_DYN_PENDULUM_EULER: n = 2; break;
     case DQP_DYN_PENDULUM_DX: n = 3; break;
+    case DQP_DYN_REXQUADROTOR: n = 12; m = 4; break;
     default: return DQP_ERR_BAD_ARG;
     }
     if (n_state) *n_state = n;
@@ -190,6 +191,7 @@ __attribute__((visibility("default"))) int dqp_dyn_step(int id, int32_t n, const
     case DQP_DYN_CARTPOLE1L: return run_step<Robot<Cartpole1l>>(n, x, u, dt, x_next, stream);
     case DQP_DYN_CARTPOLE2L: return run_step<Robot<Cartpole2l>>(n, x, u, dt, x_next, stream);
     case DQP_DYN_PENDULUM_EULER: return run_step<PendulumEuler>(n, x, u, dt, x_next, stream);
+    case DQP_DYN_REXQUADROTOR: return run_step<RexQuadrotor>(n, x, u, dt, x_next, stream);
     default: return run_step<PendulumDx>(n, x, u, dt, x_next, stream);
     }
 }
@@ -207,6 +209,7 @@ __attribute__((visibility("default"))) int dqp_dyn_jacobian(int id, int32_t n, c
     case DQP_DYN_CARTPOLE1L: return run_jac<Robot<Cartpole1l>, 5>(n, x, u, dt, x_next, Jx, Ju, stream);
     case DQP_DYN_CARTPOLE2L: return run_jac<Robot<Cartpole2l>, 4>(n, x, u, dt, x_next, Jx, Ju, stream);
     case DQP_DYN_PENDULUM_EULER: return run_jac<PendulumEuler, 3>(n, x, u, dt, x_next, Jx, Ju, stream);
+    case DQP_DYN_REXQUADROTOR: return run_jac<RexQuadrotor, 4>(n, x, u, dt, x_next, Jx, Ju, stream);
     default: return run_jac<PendulumDx, 4>(n, x, u, dt, x_next, Jx, Ju, stream);
     }
 }

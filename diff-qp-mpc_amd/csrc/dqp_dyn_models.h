@@ -18,6 +18,7 @@
 //   pendulum_euler: deqmpc/envs.py:5-47 (semi-implicit Euler, thdd = u + 10 sin th, dt given)
 //   pendulum_dx:    qpth/env_dx/pendulum.py:49-83 (state (cos th, sin th, thd), g=10, m=l=1,
 //                   u clamped to +-2, explicit Euler on thd then th)
+//   rexquadrotor:   deqmpc/rex_quadrotor.py:51-129 (12 states, 4 motors, MRP attitude, RK4)
 //
 // Everything is templated on the scalar type so that the same code evaluates values (double) and
 // forward-mode derivatives (Dual<K>: K directional derivatives ride along in registers).
@@ -234,6 +235,102 @@ struct PendulumDx {               // qpth/env_dx/pendulum.py:49-83 (simple=True,
         S s, c;
         sincos_(nth, s, c);
         xn[0] = c; xn[1] = s; xn[2] = ndth;
+    }
+};
+
+
+// deqmpc/rex_quadrotor.py:51-129 (RexQuadrotor_dynamics, default parameters): rigid body with
+// position r (world), attitude as modified Rodrigues parameters m, body-frame velocity v and rate w;
+// x = [r, m, v, w], u = four motor commands (scaled by act_scale = 100 inside the model), classic
+// RK4 with the command held.  The module stores its constants as float32 tensors and promotes them
+// when the state is double: the literals below are those float32 values.
+struct RexQuadrotor {
+    static constexpr int NX = 12, NU = 4;
+    template <class S> __host__ __device__ static void cross3(const S *a, const S *b, S *o)
+    {
+        o[0] = a[1] * b[2] - a[2] * b[1];
+        o[1] = a[2] * b[0] - a[0] * b[2];
+        o[2] = a[0] * b[1] - a[1] * b[0];
+    }
+    // rotate r by the quaternion (qs, qv): rexquad_utils.py:211-220
+    template <class S> __host__ __device__ static void quatrot(const S &qs, const S *qv, const S *r, S *o)
+    {
+        const S a = qs * qs - (qv[0] * qv[0] + qv[1] * qv[1] + qv[2] * qv[2]);
+        const S d = 2.0 * (qv[0] * r[0] + qv[1] * r[1] + qv[2] * r[2]);
+        S c[3];
+        cross3(qv, r, c);
+        const S s2 = 2.0 * qs;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) o[i] = a * r[i] + qv[i] * d + s2 * c[i];
+    }
+    // us = act_scale * u
+    template <class S> __host__ __device__ static void deriv(const S *x, const S *us, S *dx)
+    {
+        constexpr double kf = 0.0244101, km = 0.00029958, bf = -30.48576, L = 0.28, mass = 2.0;
+        constexpr double ssv = 0.7071067690849304;                       // float32(1/sqrt 2)
+        constexpr double J00 = 1.5660889446735382e-02, J01 = 3.1803699584997958e-06, J11 = 1.5620780177414417e-02,
+                         J22 = 2.2268680855631828e-02;
+        constexpr double I00 = 6.3853336334228516e+01, I01 = -1.3000453822314739e-02, I11 = 6.4017295837402344e+01,
+                         I22 = 4.4906116485595703e+01;
+        constexpr double mg = -19.6200008392334, Bfz = -121.94303894042969;   // mass * float32(-9.81), float32(4 bf)
+        const S *m = x + 3, *v = x + 6, *w = x + 9;
+        // mrp -> quaternion (rexquad_utils.py:297-300)
+        const S sq = m[0] * m[0] + m[1] * m[1] + m[2] * m[2];
+        const S inv = S(1.0) / (1.0 + sq);
+        const S qs = (1.0 - sq) * inv;
+        S qv[3], qn[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { qv[i] = 2.0 * m[i] * inv; qn[i] = -qv[i]; }
+        // forces (rex_quadrotor.py:51-68): thrust + gravity rotated into the body frame + motor bias
+        S grav[3] = {S(0.0), S(0.0), S(mg)}, f[3];
+        quatrot(qs, qn, grav, f);
+        f[2] = f[2] + kf * (us[0] + us[1] + us[2] + us[3]) + Bfz;
+        // moments (rex_quadrotor.py:70-85): arm x thrust of each motor + yaw drag torque
+        S c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = kf * us[i] + bf;
+        const double a = L * ssv;
+        S tau[3];
+        tau[0] = a * c[0] - a * c[1] - a * c[2] + a * c[3];              // sum_i (L ss_i)_y c_i
+        tau[1] = -(a * c[0] + a * c[1] - a * c[2] - a * c[3]);           // -sum_i (L ss_i)_x c_i
+        tau[2] = km * us[0] - km * us[1] + km * us[2] - km * us[3];
+        // kinematics (rexquad_utils.py:393-402) and rigid-body equations (rex_quadrotor.py:114-129)
+        quatrot(qs, qv, v, dx);
+        const S m00 = m[0] * m[0], m11 = m[1] * m[1], m22 = m[2] * m[2];
+        dx[3] = 0.25 * ((1.0 + m00 - m11 - m22) * w[0] + 2.0 * (m[0] * m[1] - m[2]) * w[1] + 2.0 * (m[0] * m[2] + m[1]) * w[2]);
+        dx[4] = 0.25 * (2.0 * (m[1] * m[0] + m[2]) * w[0] + (1.0 - m00 + m11 - m22) * w[1] + 2.0 * (m[1] * m[2] - m[0]) * w[2]);
+        dx[5] = 0.25 * (2.0 * (m[2] * m[0] - m[1]) * w[0] + 2.0 * (m[2] * m[1] + m[0]) * w[1] + (1.0 - m00 - m11 + m22) * w[2]);
+        S wv[3], Jw[3], wJw[3];
+        cross3(w, v, wv);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dx[6 + i] = f[i] * (1.0 / mass) - wv[i];
+        Jw[0] = J00 * w[0] + J01 * w[1];
+        Jw[1] = J01 * w[0] + J11 * w[1];
+        Jw[2] = J22 * w[2];
+        cross3(w, Jw, wJw);
+        const S t0 = tau[0] - wJw[0], t1 = tau[1] - wJw[1], t2 = tau[2] - wJw[2];
+        dx[9] = I00 * t0 + I01 * t1;
+        dx[10] = I01 * t0 + I11 * t1;
+        dx[11] = I22 * t2;
+    }
+    template <class S> __host__ __device__ static void step(const S *x, const S *u, double dt, S *xn)
+    {
+        S us[NU], k1[NX], k2[NX], k3[NX], k4[NX], y[NX];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) us[i] = 100.0 * u[i];
+        const double h2 = 0.5 * dt;
+        deriv(x, us, k1);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + h2 * k1[i];
+        deriv(y, us, k2);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + h2 * k2[i];
+        deriv(y, us, k3);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) y[i] = x[i] + dt * k3[i];
+        deriv(y, us, k4);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = x[i] + (dt / 6.0) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
     }
 };
 

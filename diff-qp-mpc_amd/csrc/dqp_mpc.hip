@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void assemble_backward_kernel(MpcP P)
 // sample that already improved is recomputed with the same alpha, so the outcome per sample is
 // what this loop gives, including the reference's quirk that a sample that never improves returns
 // its last trial together with an alpha decayed once more.)
-constexpr int LS_MAXN = 8, LS_MAXM = 8;
+constexpr int LS_MAXN = 12, LS_MAXM = 8;
 struct LsP {
     const double *F, *f, *x0, *x, *u, *du, *C, *c;
     double *xn, *un, *alpha, *cost;
@@ -228,6 +228,7 @@ __global__ __launch_bounds__(64) void line_search_kernel(LsP P)
                 case DQP_DYN_CARTPOLE1L: ls_step<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(xs, us, P.dt, nx); break;
                 case DQP_DYN_CARTPOLE2L: ls_step<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(xs, us, P.dt, nx); break;
                 case DQP_DYN_PENDULUM_EULER: ls_step<dqp::dyn::PendulumEuler>(xs, us, P.dt, nx); break;
+                case DQP_DYN_REXQUADROTOR: ls_step<dqp::dyn::RexQuadrotor>(xs, us, P.dt, nx); break;
                 default: ls_step<dqp::dyn::PendulumDx>(xs, us, P.dt, nx); break;
                 }
             }
@@ -254,18 +255,28 @@ template <class Map>
 __device__ __forceinline__ void vjp_step(const double *xs, const double *us, double dt, const double *lam,
                                          double *gx, double *gu)
 {
-    constexpr int NX = Map::NX, NU = Map::NU, K = NX + NU;
-    using S = dqp::dyn::Dual<K>;
-    S xa[NX], ua[NU], o[NX];
+    // forward-mode seeds in chunks of KC directions (all at once for the small models; a 16-seed
+    // dual of the 12-state RK4 step would not fit the register file)
+    constexpr int NX = Map::NX, NU = Map::NU, K = NX + NU, KC = K <= 8 ? K : 4;
+    using S = dqp::dyn::Dual<KC>;
 #pragma unroll
-    for (int k = 0; k < NX; ++k) { xa[k] = S(xs[k]); xa[k].d[k] = 1.0; }
+    for (int c0 = 0; c0 < K; c0 += KC) {
+        S xa[NX], ua[NU], o[NX];
 #pragma unroll
-    for (int k = 0; k < NU; ++k) { ua[k] = S(us[k]); ua[k].d[NX + k] = 1.0; }
-    Map::template step<S>(xa, ua, dt, o);
+        for (int k = 0; k < NX; ++k) { xa[k] = S(xs[k]); if (k >= c0 && k < c0 + KC) xa[k].d[k - c0] = 1.0; }
 #pragma unroll
-    for (int c = 0; c < NX; ++c) { double a = 0.0; for (int r = 0; r < NX; ++r) a += o[r].d[c] * lam[r]; gx[c] = a; }
+        for (int k = 0; k < NU; ++k) { ua[k] = S(us[k]); if (NX + k >= c0 && NX + k < c0 + KC) ua[k].d[NX + k - c0] = 1.0; }
+        Map::template step<S>(xa, ua, dt, o);
 #pragma unroll
-    for (int c = 0; c < NU; ++c) { double a = 0.0; for (int r = 0; r < NX; ++r) a += o[r].d[NX + c] * lam[r]; gu[c] = a; }
+        for (int c = 0; c < KC; ++c) {
+            const int col = c0 + c;
+            double a = 0.0;
+#pragma unroll
+            for (int r = 0; r < NX; ++r) a += o[r].d[c] * lam[r];
+            if (col < NX) gx[col] = a;
+            else if (col < K) gu[col - NX] = a;
+        }
+    }
 }
 
 __global__ __launch_bounds__(64) void rollout_backward_kernel(RbP P)
@@ -298,6 +309,7 @@ __global__ __launch_bounds__(64) void rollout_backward_kernel(RbP P)
             case DQP_DYN_CARTPOLE1L: vjp_step<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(xs, us, P.dt, lam, gx, gu); break;
             case DQP_DYN_CARTPOLE2L: vjp_step<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(xs, us, P.dt, lam, gx, gu); break;
             case DQP_DYN_PENDULUM_EULER: vjp_step<dqp::dyn::PendulumEuler>(xs, us, P.dt, lam, gx, gu); break;
+            case DQP_DYN_REXQUADROTOR: vjp_step<dqp::dyn::RexQuadrotor>(xs, us, P.dt, lam, gx, gu); break;
             default: vjp_step<dqp::dyn::PendulumDx>(xs, us, P.dt, lam, gx, gu); break;
             }
         }

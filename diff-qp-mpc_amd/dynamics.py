@@ -1,7 +1,7 @@
 """Device dynamics registry: the robots and pendulum modules the reference evaluates through
 per-robot torch extensions (deqmpc/my_envs/{pendulum1l,cartpole1l,cartpole2l}, Python wrappers
 deqmpc/my_envs/dynamics.py:15-263) or torch modules (deqmpc/envs.py:5-82,
-qpth/env_dx/pendulum.py:18-83), as HIP kernels behind the C ABI (include/dqp.h dqp_dyn_*).
+qpth/env_dx/pendulum.py:18-83, deqmpc/rex_quadrotor.py:7-129), as HIP kernels behind the C ABI (include/dqp.h dqp_dyn_*).
 
     dyn = DeviceDynamics("cartpole1l", dt=0.05)
     x_next = dyn(x, u)                       # the `dx` callable of the MPC layers (differentiable)
@@ -21,7 +21,7 @@ from . import _lib
 
 NAMES = tuple(_lib.DQP_DYN)
 DEFAULT_DT = {"pendulum1l": 0.05, "cartpole1l": 0.05, "cartpole2l": 0.05, "pendulum_euler": 0.05,
-              "pendulum_dx": 0.05}
+              "pendulum_dx": 0.05, "rexquadrotor": 0.05}
 
 
 def _ptr(t):
@@ -75,7 +75,8 @@ class DeviceDynamics(torch.nn.Module):
         n, m = ctypes.c_int32(0), ctypes.c_int32(0)
         _lib.check(_lib.load().dqp_dyn_sizes(self.id, ctypes.byref(n), ctypes.byref(m)), "dqp_dyn_sizes")
         self.n_state, self.n_ctrl = n.value, m.value
-        self.nx, self.nu, self.nq = self.n_state, self.n_ctrl, self.n_state // 2
+        self.nx, self.nu = self.n_state, self.n_ctrl
+        self.nq = 7 if name == "rexquadrotor" else self.n_state // 2      # rex_quadrotor.py:163
 
     # ---- raw kernels on contiguous fp64 device tensors
     def _step(self, x64, u64):

@@ -327,10 +327,12 @@ int dqp_al_merit(const dqp_al_mpc_dims *dims, int32_t ncand, const double *xu, c
  * needs, al_utils.py:458,477-480), status (B) 1.0 where the last line search accepted its step,
  * fail (one int32) != 0 when a Cholesky factorisation broke down (the reference then switches the
  * whole batch to an LU solve, al_utils.py:419-427: the caller re-runs its general path).
- * n_state <= 8, n_ctrl <= 2; nz <= 128 for the dense form (banded == 0), where L is (B,nz,nz);
- * with banded != 0, L is the buffer of dqp_al_banded_factor_bytes (see below).
+ * Dense form (banded == 0): n_state <= 8, n_ctrl <= 2, nz <= 128, L is (B,nz,nz).
+ * Banded form (banded != 0): n_state <= 12, n_state + n_ctrl <= 16, any T (BASELINE config 4:
+ * n 12, m 4, T 30, nz 480); L is the buffer of dqp_al_banded_factor_bytes (see below).
+ * The workspace size depends on the form.
  */
-size_t dqp_al_newton_solve_bytes(const dqp_al_mpc_dims *dims);
+size_t dqp_al_newton_solve_bytes(const dqp_al_mpc_dims *dims, int32_t banded);
 int dqp_al_newton_solve(const dqp_al_mpc_dims *dims, int dyn_id, double dt, int32_t n_steps, int32_t banded,
                         const double *x0, const double *Qdiag, const double *q, const double *lam,
                         const double *rho, const double *u_lower, const double *u_upper, double *xu, double *L,
@@ -374,13 +376,17 @@ int dqp_al_banded_solve(const dqp_al_mpc_dims *dims, int dyn_id, const void *fac
  *   DQP_DYN_PENDULUM_EULER   deqmpc/envs.py:5-47 PendulumDynamics (n_state 2, semi-implicit Euler)
  *   DQP_DYN_PENDULUM_DX      qpth/env_dx/pendulum.py:18-83 PendulumDx, simple=True, default
  *       parameters (n_state 3: cos th, sin th, thdot; control clamped to +-2)
+ *   DQP_DYN_REXQUADROTOR     deqmpc/rex_quadrotor.py:7-129 RexQuadrotor_dynamics, default parameters
+ *       (BASELINE config 4: n_state 12 = position, MRP attitude, body velocity, body rate;
+ *       n_ctrl 4 motor commands; RK4)
  */
 enum {
     DQP_DYN_PENDULUM1L = 1,
     DQP_DYN_CARTPOLE1L = 2,
     DQP_DYN_CARTPOLE2L = 3,
     DQP_DYN_PENDULUM_EULER = 4,
-    DQP_DYN_PENDULUM_DX = 5
+    DQP_DYN_PENDULUM_DX = 5,
+    DQP_DYN_REXQUADROTOR = 6
 };
 
 /* n_state / n_ctrl of a registered model; DQP_ERR_BAD_ARG for an unknown id. */

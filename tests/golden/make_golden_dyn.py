@@ -77,3 +77,19 @@ for i in range(3):
 np.savez_compressed(os.path.join(HERE, "DYN_pendulum_dx.npz"), x=x.numpy(), u=u.numpy(), dt=pdx.dt,
                     x_next=xn.detach().numpy(), Jx=Jx.numpy(), Ju=Ju.numpy())
 print("pendulum_dx ok")
+
+# deqmpc/rex_quadrotor.py (BASELINE config 4): the torch module and its autograd Jacobian class, built
+# under the default float32 dtype like the reference's scripts (its constants are float32 tensors),
+# evaluated on float64 states
+torch.set_default_dtype(torch.float32)
+from rex_quadrotor import RexQuadrotor_dynamics, RexQuadrotor_dynamics_jac  # noqa: E402
+qd_, qj_ = RexQuadrotor_dynamics(), RexQuadrotor_dynamics_jac()
+torch.set_default_dtype(torch.float64)
+rng = np.random.default_rng(11)
+win = np.array([5.0] * 3 + [0.4] * 3 + [0.5] * 3 + [0.25] * 3)
+x = torch.tensor(rng.uniform(-1, 1, (N, 12)) * win); u = torch.tensor(rng.uniform(11.5, 18.3, (N, 4)))
+xn = qd_(x, u)
+xj, (Jx, Ju) = qj_(x.clone().requires_grad_(), u.clone().requires_grad_())
+np.savez_compressed(os.path.join(HERE, "DYN_rexquadrotor.npz"), x=x.numpy(), u=u.numpy(), dt=qd_.dt,
+                    x_next=xn.numpy(), Jx=Jx.detach().numpy(), Ju=Ju.detach().numpy())
+print("rexquadrotor ok", float((xj - xn).abs().max()), float(xn.abs().max()))

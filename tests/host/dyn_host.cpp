@@ -33,6 +33,7 @@ extern "C" __attribute__((visibility("default"))) int dyn_host_jac(int id, int N
     case 3: jac<Robot<Cartpole2l>>(N, x, u, dt, xn, Jx, Ju); return 0;
     case 4: jac<PendulumEuler>(N, x, u, dt, xn, Jx, Ju); return 0;
     case 5: jac<PendulumDx>(N, x, u, dt, xn, Jx, Ju); return 0;
+    case 6: jac<RexQuadrotor>(N, x, u, dt, xn, Jx, Ju); return 0;
     }
     return -1;
 }

@@ -236,12 +236,15 @@ def test_al_mpc_two_calls_vs_reference(name):
     np.testing.assert_allclose(ctrl.rho_prev.cpu().numpy(), g["rho2"], rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("name,robot", [("CFG3_cartpole1l_T20_b4", "cartpole1l"), ("CFG5_cartpole2l_T5_b4", "cartpole2l")])
+@pytest.mark.parametrize("name,robot", [("CFG3_cartpole1l_T20_b4", "cartpole1l"), ("CFG5_cartpole2l_T5_b4", "cartpole2l"),
+                                        ("CFG4_rexquadrotor_T30_b4", "rexquadrotor"),
+                                        ("CFG4_rexquadrotor_T6_b4", "rexquadrotor")])
 def test_al_mpc_cartpole_vs_reference(name, robot):
-    """BASELINE config 3 (cartpole-1, n 4, m 1, T 20) and the config-5 robot (cartpole-2, n 6, T 5)
+    """BASELINE config 3 (cartpole-1, n 4, m 1, T 20), the config-5 robot (cartpole-2, n 6, T 5) and
+    config 4 (quadrotor, n 12, m 4, T 30: nz = 480, and a T = 6 case)
     through AL_mpc.MPC with the DEVICE dynamics registry, against the reference's AL_mpc.MPC run on
-    its own CasADi-generated dynamics (make_golden_cfg3.py): cold call with gradients, then the
-    warm-started call.  x, u are float32 in the reference (AL_mpc.py:319-320): rtol 1e-4 / atol 1e-4
+    its own dynamics (CasADi-generated C: make_golden_cfg3.py; rex_quadrotor.py: make_golden_cfg4.py):
+    cold call with gradients, then the warm-started call.  x, u are float32 in the reference (AL_mpc.py:319-320): rtol 1e-4 / atol 1e-4
     (states reach +-pi, controls +-100); multipliers rtol 1e-5 / atol 1e-5; rho exact."""
     from diff_qp_mpc_amd import AL_mpc, al_utils
     from diff_qp_mpc_amd.dynamics import DeviceDynamics
@@ -312,7 +315,7 @@ def test_config3_full_size_properties():
 
 
 @pytest.mark.parametrize("robot,T", [("pendulum_euler", 20), ("cartpole1l", 20), ("cartpole2l", 5), ("pendulum_dx", 10),
-                                     ("pendulum1l", 3)])
+                                     ("pendulum1l", 3), ("rexquadrotor", 30), ("rexquadrotor", 4)])
 def test_banded_newton_step_vs_dense_oracle(robot, T):
     """dqp_al_banded_newton_step (block-tridiagonal Cholesky, every knot in registers) against the
     reference's dense formulation restated in numpy (oracle/al_oracle.py: dense constraint Jacobian,
@@ -329,6 +332,8 @@ def test_banded_newton_step_vs_dense_oracle(robot, T):
     gen = torch.Generator().manual_seed(T)
     rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).cuda()
     xu = 0.5 * rnd(B, T, nt)
+    if robot == "rexquadrotor":
+        xu[..., n:] = 14.5 + 0.3 * rnd(B, T, m)          # around hover; bounds below are +-0.3 about it
     if robot == "pendulum_dx":
         xu[..., :2] = torch.nn.functional.normalize(xu[..., :2], dim=-1)
     x0 = xu[:, 0, :n] + 0.1 * rnd(B, n)
@@ -337,7 +342,8 @@ def test_banded_newton_step_vs_dense_oracle(robot, T):
     ncon = T * n + 2 * T * m
     lam = rnd(B, ncon)
     rho = (10.0 ** torch.randint(0, 3, (B, 1), generator=gen).double()).cuda()
-    lo, hi = torch.full((m,), -0.3, dtype=torch.float64).cuda(), torch.full((m,), 0.3, dtype=torch.float64).cuda()
+    mid = 14.5 if robot == "rexquadrotor" else 0.0
+    lo, hi = torch.full((m,), mid - 0.3, dtype=torch.float64).cuda(), torch.full((m,), mid + 0.3, dtype=torch.float64).cuda()
 
     def step_np(x, u):
         xn, (Jx, Ju) = dyn.jac(dev(x), dev(u))

@@ -13,7 +13,7 @@ from oracle import dyn_ref
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-NAMES = ["pendulum1l", "cartpole1l", "cartpole2l", "pendulum_euler", "pendulum_dx"]
+NAMES = ["pendulum1l", "cartpole1l", "cartpole2l", "pendulum_euler", "pendulum_dx", "rexquadrotor"]
 
 
 def dev(a):
@@ -87,6 +87,8 @@ def test_autograd_through_the_step(dynmod, name):
     if name == "pendulum_dx":
         x[:, :2] = torch.nn.functional.normalize(x[:, :2], dim=1)
     u = torch.randn(16, dyn.n_ctrl, dtype=torch.float64, device="cuda", generator=g)
+    if name == "rexquadrotor":
+        x, u = 0.3 * x, 14.5 + u
     w = torch.randn(16, dyn.n_state, dtype=torch.float64, device="cuda", generator=g)
     xr, ur = x.clone().requires_grad_(), u.clone().requires_grad_()
     (dyn(xr, ur) * w).sum().backward()
@@ -95,8 +97,10 @@ def test_autograd_through_the_step(dynmod, name):
         d = torch.zeros_like(x); d[:, j] = e
         fd = ((dyn(x + d, u) - dyn(x - d, u)) * w).sum(1) / (2 * e)
         np.testing.assert_allclose(xr.grad[:, j].cpu().numpy(), fd.cpu().numpy(), rtol=1e-6, atol=1e-7)
-    fd = ((dyn(x, u + e) - dyn(x, u - e)) * w).sum(1) / (2 * e)
-    np.testing.assert_allclose(ur.grad[:, 0].cpu().numpy(), fd.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    for j in range(dyn.n_ctrl):
+        d = torch.zeros_like(u); d[:, j] = e
+        fd = ((dyn(x, u + d) - dyn(x, u - d)) * w).sum(1) / (2 * e)
+        np.testing.assert_allclose(ur.grad[:, j].cpu().numpy(), fd.cpu().numpy(), rtol=1e-6, atol=1e-7)
 
 
 def test_bad_arguments(dynmod):
