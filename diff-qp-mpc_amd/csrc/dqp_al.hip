@@ -619,11 +619,14 @@ struct LsAP {
 };
 
 // merit (al_utils.py:37-59) of ncand candidates xu + 2^-k upd per problem (x_0 pinned to x0,
-// al_utils.py:515), dynamics evaluated in the kernel; 16 lanes per (candidate, problem).  ncand = 0
-// evaluates the current point (step 0) into merit[b].
+// al_utils.py:515), dynamics evaluated in the kernel; 16 lanes per (candidate, problem), one knot
+// per lane and round, sizes compile-time so that a knot lives in registers.  ncand = 0 evaluates
+// the current point (step 0) into merit[b].
+template <class Map>
 __global__ __launch_bounds__(256) void al_ls_kernel(LsAP P)
 {
-    const int n = P.n, m = P.m, T = P.T, nt = n + m, neq = T * n, ncon = neq + 2 * T * m;
+    constexpr int n = Map::NX, m = Map::NU, nt = n + m;
+    const int T = P.T, neq = T * n, ncon = neq + 2 * T * m;
     const int nc = P.ncand > 0 ? P.ncand : 1;
     const long long item = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int r = threadIdx.x & 15;
@@ -638,31 +641,26 @@ __global__ __launch_bounds__(256) void al_ls_kernel(LsAP P)
     const double rho = P.rho[b];
     double acc = 0.0;
     for (int t = r; t < T; t += 16) {
-        double z[16], zn[12], xn[12];
+        double z[nt], xn[n];
+#pragma unroll
         for (int j = 0; j < nt; ++j) z[j] = xu[t * nt + j] + step * up[t * nt + j];
-        if (t == 0) for (int j = 0; j < n; ++j) z[j] = x0[j];
+        if (t == 0) {
+#pragma unroll
+            for (int j = 0; j < n; ++j) z[j] = x0[j];
+        }
+#pragma unroll
         for (int j = 0; j < nt; ++j) acc += (0.5 * Qd[t * nt + j] * z[j] + q[t * nt + j]) * z[j];
         if (t < T - 1) {
-            switch (P.dyn) {
-            case DQP_DYN_PENDULUM1L: step_knot<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>(z, z + n, P.dt, xn); break;
-            case DQP_DYN_CARTPOLE1L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(z, z + n, P.dt, xn); break;
-            case DQP_DYN_CARTPOLE2L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(z, z + n, P.dt, xn); break;
-            case DQP_DYN_PENDULUM_EULER: step_knot<dqp::dyn::PendulumEuler>(z, z + n, P.dt, xn); break;
-            case DQP_DYN_REXQUADROTOR: step_knot<dqp::dyn::RexQuadrotor>(z, z + n, P.dt, xn); break;
-            default: step_knot<dqp::dyn::PendulumDx>(z, z + n, P.dt, xn); break;
-            }
+            Map::template step<double>(z, z + n, P.dt, xn);
+#pragma unroll
             for (int j = 0; j < n; ++j) {
-                zn[j] = xu[(t + 1) * nt + j] + step * up[(t + 1) * nt + j];
-                const double res = zn[j] - xn[j];
+                const double zn = xu[(t + 1) * nt + j] + step * up[(t + 1) * nt + j];
+                const double res = zn - xn[j];
                 acc += (0.5 * rho * res + lam[t * n + j]) * res;
             }
-        } else {
-            for (int j = 0; j < n; ++j) {
-                const double first = x0[j];                      // the pinned x_0
-                const double res = first - x0[j];
-                acc += (0.5 * rho * res + lam[(T - 1) * n + j]) * res;
-            }
         }
+        // (the x_0 rows contribute nothing: x_0 is pinned to x0, their residual is exactly zero)
+#pragma unroll
         for (int i = 0; i < m; ++i) {
             const double u = z[n + i], hi = u - P.uu[i], lo = P.ul[i] - u;
             const int row = neq + t * 2 * m + i;
@@ -671,6 +669,22 @@ __global__ __launch_bounds__(256) void al_ls_kernel(LsAP P)
     }
     acc = dqp::r16::row_sum(acc);
     if (r == 0 && item < total) P.merit[item] = acc;
+}
+
+int launch_ls(const LsAP &P, hipStream_t st)
+{
+    const long long items = (long long)(P.ncand > 0 ? P.ncand : 1) * P.B;
+    const dim3 grid((unsigned)((items + 15) / 16)), block(256);
+    switch (P.dyn) {
+    case DQP_DYN_PENDULUM1L: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE1L: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE2L: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_EULER: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::PendulumEuler>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_DX: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::PendulumDx>, grid, block, 0, st, P); break;
+    case DQP_DYN_REXQUADROTOR: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::RexQuadrotor>, grid, block, 0, st, P); break;
+    default: return DQP_ERR_BAD_ARG;
+    }
+    return DQP_OK;
 }
 
 struct OutP {
@@ -896,13 +910,13 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
         int32_t *info = (int32_t *)w;
         if (hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
         LsAP Lp = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit_cur, dt, B, n, m, T, 0, dyn_id};
-        hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, Lp);   // merit at the start
+        launch_ls(Lp, st);                                              // merit at the start
         for (int it = 0; it < n_steps; ++it) {
             int rc = dqp_al_banded_newton_step(d, dyn_id, dt, xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, upd, L,
                                                info, stream);
             if (rc) return rc;
             LsAP Lc = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, dt, B, n, m, T, 20, dyn_id};
-            hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)(((long long)20 * B + 15) / 16)), dim3(256), 0, st, Lc);
+            launch_ls(Lc, st);
             SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
             hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
         }
@@ -925,7 +939,7 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
     int32_t *info = (int32_t *)w;
     if (hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
     LsAP Lp = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit_cur, dt, B, n, m, T, 0, dyn_id};
-    hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, Lp);   // merit at the start
+    launch_ls(Lp, st);                                                  // merit at the start
     for (int it = 0; it < n_steps; ++it) {
         LinP Li = {xu, x0, u_lower, u_upper, Jx, Ju, resc, dt, B, n, m, T, dyn_id};
         hipLaunchKernelGGL(al_linearize_kernel, dim3((unsigned)(((long long)B * T + 255) / 256)), dim3(256), 0, st, Li);
@@ -945,7 +959,7 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
         }
         if (rc) return rc;
         LsAP Lc = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, dt, B, n, m, T, 20, dyn_id};
-        hipLaunchKernelGGL(al_ls_kernel, dim3((unsigned)(((long long)20 * B + 15) / 16)), dim3(256), 0, st, Lc);
+        launch_ls(Lc, st);
         SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
         hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
     }

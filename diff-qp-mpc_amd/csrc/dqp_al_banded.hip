@@ -110,30 +110,29 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             }
         }
         // ---- gradient element r of this knot, and the diagonal terms of H_tt
-        double zr = 0.0, qdr = 0.0, qr = 0.0;
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            if (r == j) { zr = z[j]; qdr = Qd[t * NT + j]; qr = q[t * NT + j]; }
+        // (per-lane addresses: one coalesced load each instead of NT predicated ones)
+        const int rr = inT ? r : 0;
+        const double zr = xu[t * NT + rr], qdr = Qd[t * NT + rr], qr = q[t * NT + rr];
         double g = qdr * zr + qr, dg = qdr;
 #pragma unroll
         for (int j = 0; j < NX; ++j) g -= Jc[j] * mu[j];
-        if (r < NX) {
-            double inc = 0.0;                       // + I block of the previous dynamics rows / the x_0 rows
+        {
+            // x rows: + I block of the previous dynamics rows / the x_0 rows; u rows: the box rows
+            const int rx = r < NX ? r : 0, i = (inT && r >= NX) ? r - NX : 0;
+            double prev = 0.0;
 #pragma unroll
-            for (int j = 0; j < NX; ++j)
-                if (r == j) inc = (t > 0) ? mu_prev[j] : lam[(T - 1) * NX + j] + rho * (z[j] - x0[j]);
-            g += inc;
-            dg += rho;
-        } else if (inT) {
-            const int i = r - NX;
-            double u = 0.0, hi = 0.0, lo = 0.0;
-#pragma unroll
-            for (int k = 0; k < NU; ++k)
-                if (i == k) { u = z[NX + k]; hi = P.uu[k]; lo = P.ul[k]; }
-            const double rup = u - hi, rlo = lo - u;
+            for (int j = 0; j < NX; ++j) prev = (r == j) ? mu_prev[j] : prev;
+            const double first = lam[(T - 1) * NX + rx] + rho * (zr - x0[rx]);
             const int row = neq + t * 2 * NU + i;
-            g += (lam[row] + rho * fmax(rup, 0.0)) - (lam[row + NU] + rho * fmax(rlo, 0.0));
-            dg += rho * ((rup > 0.0 ? 1.0 : 0.0) + (rlo > 0.0 ? 1.0 : 0.0));
+            const double rup = zr - P.uu[i], rlo = P.ul[i] - zr;
+            const double lup = lam[row], llo = lam[row + NU];
+            if (r < NX) {
+                g += (t > 0) ? prev : first;
+                dg += rho;
+            } else if (inT) {
+                g += (lup + rho * fmax(rup, 0.0)) - (llo + rho * fmax(rlo, 0.0));
+                dg += rho * ((rup > 0.0 ? 1.0 : 0.0) + (rlo > 0.0 ? 1.0 : 0.0));
+            }
         }
         // ---- H_tt row r:  rho J^T J + diag - Gram(M_prev) on the x-x block
         double H[1][NT], rd[1];
