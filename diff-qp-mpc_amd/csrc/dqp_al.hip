@@ -619,17 +619,21 @@ struct LsAP {
 };
 
 // merit (al_utils.py:37-59) of ncand candidates xu + 2^-k upd per problem (x_0 pinned to x0,
-// al_utils.py:515), dynamics evaluated in the kernel; 16 lanes per (candidate, problem), one knot
-// per lane and round, sizes compile-time so that a knot lives in registers.  ncand = 0 evaluates
-// the current point (step 0) into merit[b].
+// al_utils.py:515), dynamics evaluated in the kernel; 16 lanes per (candidate, problem).  ncand = 0
+// evaluates the current point (step 0) into merit[b].  Knots are processed 16 at a time:
+//   phase A  element-wise over the entries of knots c .. c+16, lanes along the contiguous axis
+//            (coalesced): z = xu + step upd -> LDS; cost and box-constraint terms of knots c .. c+15
+//   phase B  one knot per lane: the model step from the knot in LDS (odd stride: conflict-free),
+//            residual against the next knot in LDS, multiplier and penalty terms
 template <class Map>
 __global__ __launch_bounds__(256) void al_ls_kernel(LsAP P)
 {
-    constexpr int n = Map::NX, m = Map::NU, nt = n + m;
+    constexpr int n = Map::NX, m = Map::NU, nt = n + m, ZS = nt | 1;
+    __shared__ double ls_lds[16 * 17 * ZS];
     const int T = P.T, neq = T * n, ncon = neq + 2 * T * m;
     const int nc = P.ncand > 0 ? P.ncand : 1;
-    const long long item = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int r = threadIdx.x & 15;
+    const int slot = threadIdx.x >> 4, r = threadIdx.x & 15;
+    const long long item = (long long)blockIdx.x * 16 + slot;
     const long long total = (long long)nc * P.B;
     const long long it = item < total ? item : total - 1;
     const long long b = it % P.B;
@@ -639,52 +643,64 @@ __global__ __launch_bounds__(256) void al_ls_kernel(LsAP P)
     const double *Qd = P.Qd + b * (long long)T * nt, *q = P.q + b * (long long)T * nt;
     const double *lam = P.lam + b * (long long)ncon, *x0 = P.x0 + b * (long long)n;
     const double rho = P.rho[b];
+    double *zb = ls_lds + slot * 17 * ZS;
     double acc = 0.0;
-    for (int t = r; t < T; t += 16) {
-        double z[nt], xn[n];
-#pragma unroll
-        for (int j = 0; j < nt; ++j) z[j] = xu[t * nt + j] + step * up[t * nt + j];
-        if (t == 0) {
-#pragma unroll
-            for (int j = 0; j < n; ++j) z[j] = x0[j];
+    for (int c = 0; c < T; c += 16) {
+        const int kend = (c + 17 < T ? c + 17 : T) - c;                  // knots staged this round (<= 17)
+#pragma unroll 4
+        for (int e = r; e < kend * nt; e += 16) {
+            const int tl = e / nt, j = e - tl * nt, t = c + tl, ge = c * nt + e;
+            double z = xu[ge] + step * up[ge];
+            if (t == 0 && j < n) z = x0[j];
+            zb[tl * ZS + j] = z;
+            if (tl < 16) {
+                acc += (0.5 * Qd[ge] * z + q[ge]) * z;
+                if (j >= n) {
+                    const int i = j - n, row = neq + t * 2 * m + i;
+                    const double hi = z - P.uu[i], lo = P.ul[i] - z;
+                    acc += lam[row] * hi + lam[row + m] * lo +
+                           0.5 * rho * (fmax(hi, 0.0) * fmax(hi, 0.0) + fmax(lo, 0.0) * fmax(lo, 0.0));
+                }
+            }
         }
-#pragma unroll
-        for (int j = 0; j < nt; ++j) acc += (0.5 * Qd[t * nt + j] * z[j] + q[t * nt + j]) * z[j];
+        __syncthreads();
+        const int t = c + r;
         if (t < T - 1) {
+            double z[nt], xn[n];
+#pragma unroll
+            for (int j = 0; j < nt; ++j) z[j] = zb[r * ZS + j];
             Map::template step<double>(z, z + n, P.dt, xn);
 #pragma unroll
             for (int j = 0; j < n; ++j) {
-                const double zn = xu[(t + 1) * nt + j] + step * up[(t + 1) * nt + j];
-                const double res = zn - xn[j];
+                const double res = zb[(r + 1) * ZS + j] - xn[j];
                 acc += (0.5 * rho * res + lam[t * n + j]) * res;
             }
         }
-        // (the x_0 rows contribute nothing: x_0 is pinned to x0, their residual is exactly zero)
-#pragma unroll
-        for (int i = 0; i < m; ++i) {
-            const double u = z[n + i], hi = u - P.uu[i], lo = P.ul[i] - u;
-            const int row = neq + t * 2 * m + i;
-            acc += lam[row] * hi + lam[row + m] * lo + 0.5 * rho * (fmax(hi, 0.0) * fmax(hi, 0.0) + fmax(lo, 0.0) * fmax(lo, 0.0));
-        }
+        __syncthreads();
     }
+    // (the x_0 rows contribute nothing: x_0 is pinned to x0, their residual is exactly zero)
     acc = dqp::r16::row_sum(acc);
     if (r == 0 && item < total) P.merit[item] = acc;
 }
 
-int launch_ls(const LsAP &P, hipStream_t st)
+template <class Map> int launch_ls_t(const LsAP &P, hipStream_t st)
 {
     const long long items = (long long)(P.ncand > 0 ? P.ncand : 1) * P.B;
-    const dim3 grid((unsigned)((items + 15) / 16)), block(256);
+    hipLaunchKernelGGL(al_ls_kernel<Map>, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, P);
+    return DQP_OK;
+}
+
+int launch_ls(const LsAP &P, hipStream_t st)
+{
     switch (P.dyn) {
-    case DQP_DYN_PENDULUM1L: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>, grid, block, 0, st, P); break;
-    case DQP_DYN_CARTPOLE1L: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>, grid, block, 0, st, P); break;
-    case DQP_DYN_CARTPOLE2L: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>, grid, block, 0, st, P); break;
-    case DQP_DYN_PENDULUM_EULER: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::PendulumEuler>, grid, block, 0, st, P); break;
-    case DQP_DYN_PENDULUM_DX: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::PendulumDx>, grid, block, 0, st, P); break;
-    case DQP_DYN_REXQUADROTOR: hipLaunchKernelGGL(al_ls_kernel<dqp::dyn::RexQuadrotor>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM1L: return launch_ls_t<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>(P, st);
+    case DQP_DYN_CARTPOLE1L: return launch_ls_t<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(P, st);
+    case DQP_DYN_CARTPOLE2L: return launch_ls_t<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(P, st);
+    case DQP_DYN_PENDULUM_EULER: return launch_ls_t<dqp::dyn::PendulumEuler>(P, st);
+    case DQP_DYN_PENDULUM_DX: return launch_ls_t<dqp::dyn::PendulumDx>(P, st);
+    case DQP_DYN_REXQUADROTOR: return launch_ls_t<dqp::dyn::RexQuadrotor>(P, st);
     default: return DQP_ERR_BAD_ARG;
     }
-    return DQP_OK;
 }
 
 struct OutP {
@@ -910,13 +926,15 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
         int32_t *info = (int32_t *)w;
         if (hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
         LsAP Lp = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit_cur, dt, B, n, m, T, 0, dyn_id};
-        launch_ls(Lp, st);                                              // merit at the start
+        int rc0 = launch_ls(Lp, st);                                    // merit at the start
+        if (rc0) return rc0;
         for (int it = 0; it < n_steps; ++it) {
             int rc = dqp_al_banded_newton_step(d, dyn_id, dt, xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, upd, L,
                                                info, stream);
             if (rc) return rc;
             LsAP Lc = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, dt, B, n, m, T, 20, dyn_id};
-            launch_ls(Lc, st);
+            rc = launch_ls(Lc, st);
+            if (rc) return rc;
             SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
             hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
         }
@@ -939,7 +957,8 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
     int32_t *info = (int32_t *)w;
     if (hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
     LsAP Lp = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit_cur, dt, B, n, m, T, 0, dyn_id};
-    launch_ls(Lp, st);                                                  // merit at the start
+    rc = launch_ls(Lp, st);                                             // merit at the start
+    if (rc) return rc;
     for (int it = 0; it < n_steps; ++it) {
         LinP Li = {xu, x0, u_lower, u_upper, Jx, Ju, resc, dt, B, n, m, T, dyn_id};
         hipLaunchKernelGGL(al_linearize_kernel, dim3((unsigned)(((long long)B * T + 255) / 256)), dim3(256), 0, st, Li);
@@ -959,7 +978,8 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
         }
         if (rc) return rc;
         LsAP Lc = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, dt, B, n, m, T, 20, dyn_id};
-        launch_ls(Lc, st);
+        rc = launch_ls(Lc, st);
+        if (rc) return rc;
         SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
         hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
     }

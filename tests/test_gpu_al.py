@@ -314,6 +314,42 @@ def test_config3_full_size_properties():
     np.testing.assert_allclose(ctrl.lamda_prev[:4].cpu().numpy(), g["lam1"], rtol=1e-5, atol=1e-5)
 
 
+def test_config4_full_size_properties():
+    """BASELINE config 4 at its size: quadrotor n 12, m 4, T = 30 (nz = 480), B = 8192 -- one
+    AL_mpc.MPC call through the block-tridiagonal device path.  Size-independent properties as for
+    config 3, and batch-size independence against the reference: the first four problems are the
+    golden fixture's (make_golden_cfg4.py), solved here inside the 8192-batch."""
+    from diff_qp_mpc_amd import AL_mpc, al_utils
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    g = load("CFG4_rexquadrotor_T30_b4")
+    B, T, nx, nu = 8192, 30, 12, 4
+    dyn = DeviceDynamics("rexquadrotor", dt=float(g["dt"]))
+    rng = np.random.default_rng(0)
+    win = np.array([1.0] * 3 + [0.15] * 3 + [0.5] * 3 + [0.25] * 3)
+    x0 = dev(rng.uniform(-1, 1, (B, nx)) * win)
+    np.testing.assert_allclose(x0[:4].cpu().numpy(), g["in_x0"], rtol=0, atol=0)      # same generator stream
+    Qd = dev(g["in_Qd"][0, 0]).repeat(B, T, 1)
+    ramp = torch.linspace(1.0, 0.0, T, dtype=torch.float64, device="cuda")[None, :, None]
+    x_ref = x0[:, None, :] * ramp
+    u_ref = dev(g["in_u_init"][0, 0]).repeat(B, T, 1)
+    C = torch.diag_embed(Qd)
+    c = -(Qd * torch.cat([x_ref, u_ref], -1))
+    np.testing.assert_allclose(c[:4].cpu().numpy(), g["in_c"], rtol=0, atol=1e-15)
+    ctrl = AL_mpc.MPC(nx, nu, T, u_lower=dev(g["in_u_lower"]), u_upper=dev(g["in_u_upper"]), n_batch=B, verbose=0,
+                      solver_type="dense", dtype=torch.float64, eps=1e-5, exit_unconverged=False, backprop=False)
+    ctrl.reinitialize(x0, torch.ones(B, T, 1, device="cuda"))
+    ctrl.x_init, ctrl.u_init = x_ref.clone(), u_ref.clone()
+    x, u = ctrl(x0, al_utils.QuadCost(C, c), dyn, dyn.jac)
+    assert x.shape == (B, T, nx) and u.shape == (B, T, nu)
+    assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(u).all())
+    assert float((x[:, 0].double() - x0).abs().max()) < 1e-6
+    assert float(ctrl.lamda_prev[:, T * nx:].min()) >= 0.0
+    assert set(ctrl.rho_prev.unique().tolist()) <= {100.0}
+    np.testing.assert_allclose(x[:4].cpu().numpy(), g["x1"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(u[:4].cpu().numpy(), g["u1"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ctrl.lamda_prev[:4].cpu().numpy(), g["lam1"], rtol=1e-5, atol=1e-5)
+
+
 @pytest.mark.parametrize("robot,T", [("pendulum_euler", 20), ("cartpole1l", 20), ("cartpole2l", 5), ("pendulum_dx", 10),
                                      ("pendulum1l", 3), ("rexquadrotor", 30), ("rexquadrotor", 4)])
 def test_banded_newton_step_vs_dense_oracle(robot, T):
