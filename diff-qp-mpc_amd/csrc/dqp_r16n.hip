@@ -45,6 +45,11 @@ template <int N_, int M_, int E_> struct Cfg {
     static constexpr int N = N_, M = M_, E = E_, R = N_ - E_;
     static constexpr int SN = slots(N_), SM = slots(M_), SR = slots(N_ - E_);
     static constexpr int SE = E_ > 0 ? slots(E_) : 1, EC = E_ > 0 ? E_ : 1;
+    static constexpr bool PARK = slots(N_) >= 3;        // W, U leave the registers between setup and epilogue
+#ifndef DQP_R16N_PIN_ALL
+#define DQP_R16N_PIN_ALL 1
+#endif
+    static constexpr bool PIN = PARK || DQP_R16N_PIN_ALL;   // ordered setup (pin / exec-masked tail stores)
     // LDS per QP (doubles)
     static constexpr int tailsz = E_ * (N_ - E_) + E_ * (E_ - 1) / 2;     // sum_k c_k, c_k = R + k
     static constexpr int oLq = 0;                       // packed lower triangle of Lq
@@ -68,6 +73,23 @@ template <int N_, int M_, int E_> struct Cfg {
     static constexpr int wTau = wU + E_ * E_, wRdu = wTau + E_, wRdq = wRdu + E_;
     static constexpr int wsQP = wRdq + N_;
 };
+
+// Phase boundary for the compiler: LDS contents are to be re-read after this point.  Without it LLVM
+// keeps every Lq entry a phase has read from LDS alive (in AGPRs, then scratch) to reuse it in a later
+// phase that reads the same address -- for N = 40 that is the whole 820-entry triangle, i.e. the 13 KB
+// of scratch per lane the 3-slot kernels used to have.
+#define DQP_PHASE_FENCE() asm volatile("" ::: "memory")
+// x passes through a side-effecting no-op: everything that produces it is scheduled before, every
+// memory read that follows after.  (__builtin_amdgcn_sched_barrier alone orders memory operations;
+// an independent FMA chain -- e.g. the second register slot of a triangular solve -- still floats
+// past it and the LDS operands it needs later end up in scratch.)
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x) : : "memory"); }
+// the same LDS address as an unrelated pointer, as far as the optimiser can tell
+__device__ __forceinline__ const double *relabel(const double *p)
+{
+    asm volatile("" : "+v"(p));
+    return p;
+}
 
 template <class C> struct State {
     double Gh[C::SM][C::N];     // Gh Qf = [Gz | W], row-distributed by constraint
@@ -279,6 +301,58 @@ __device__ __forceinline__ void mpc_rows_A(const KParams &P, long long qp, int n
     }
 }
 
+// [Gz | W], U, tau, 1/diag(U) -> the caller's workspace (the factorisation context backward restarts
+// from).  Column-major: the 16 lanes of a QP write 16 consecutive doubles (row-major 8-byte stores
+// 240 B apart cost 5x write amplification in HBM).
+template <class C>
+__device__ __forceinline__ void park_GU(double *ws, const State<C> &st, int r)
+{
+    constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
+#pragma unroll
+    for (int s = 0; s < C::SM; ++s) {
+        const int i = r + 16 * s;
+        if (i < M) {
+#pragma unroll
+            for (int c = 0; c < N; ++c) ws[C::wG + c * M + i] = st.Gh[s][c];
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < C::SE; ++s) {
+        const int k = r + 16 * s;
+        if (k < E) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) ws[C::wU + e * E + k] = st.Ah[s][R + e];
+            ws[C::wTau + k] = st.tau[s];
+            ws[C::wRdu + k] = st.rdu1[s];
+        }
+    }
+}
+// W = Gh[:, R:] and U = Ah[:, R:] back from the workspace (3-slot sizes drop them from the register
+// file between the setup and the epilogue)
+template <class C>
+__device__ __forceinline__ void unpark_WU(const double *ws, State<C> &st, int r)
+{
+    constexpr int M = C::M, E = C::E, R = C::R;
+#pragma unroll
+    for (int s = 0; s < C::SM; ++s) {
+        const int i = r + 16 * s, ic = i < M ? i : M - 1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double v = ws[C::wG + (R + e) * M + ic];
+            st.Gh[s][R + e] = i < M ? v : 0.0;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < C::SE; ++s) {
+        const int k = r + 16 * s, kc = k < E ? k : E - 1;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const double v = ws[C::wU + e * E + kc];
+            st.Ah[s][R + e] = k < E ? v : 0.0;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 template <class C>
 __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, double *lds, State<C> &st)
@@ -328,14 +402,17 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     }
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
+    DQP_PHASE_FENCE();
     STAMP(P, 1);
 
-    // B: rows of G, A times Lq^-T (Lq[j][k] read row-uniformly from LDS)
+    // B: rows of G, A times Lq^-T (Lq[j][k] read row-uniformly from LDS).  Sizes with three register
+    // slots per N-space row (C::PARK) cannot hold Gh, Ah and a reflector at once: they do A first
+    // (B, C, D on Ah alone), then G (B, then the reflectors re-read from LDS) -- see below.
     if (mpc) {
-        mpc_rows_G<SM, N>(P, M, st.Gh, r);
+        if (!C::PARK) mpc_rows_G<SM, N>(P, M, st.Gh, r);
         if (E > 0) mpc_rows_A<SE, N>(P, qp, E, st.Ah, r);
     } else {
-        load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
+        if (!C::PARK) load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
         if (E > 0) load_rows<SE, N>(P.A + qp * P.sA, E, st.Ah, r);
     }
     {
@@ -345,26 +422,39 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
 #pragma unroll
             for (int k = 0; k < j; ++k) {
                 const double ljk = Lp[tri(j) + k];
+                if (!C::PARK) {
 #pragma unroll
-                for (int s = 0; s < SM; ++s) st.Gh[s][j] = fma(-st.Gh[s][k], ljk, st.Gh[s][j]);
+                    for (int s = 0; s < SM; ++s) st.Gh[s][j] = fma(-st.Gh[s][k], ljk, st.Gh[s][j]);
+                }
                 if (E > 0) {
 #pragma unroll
                     for (int s = 0; s < SE; ++s) st.Ah[s][j] = fma(-st.Ah[s][k], ljk, st.Ah[s][j]);
                 }
             }
             const double rj = BC(st.rdq, j);
+            if (!C::PARK) {
 #pragma unroll
-            for (int s = 0; s < SM; ++s) st.Gh[s][j] *= rj;
+                for (int s = 0; s < SM; ++s) st.Gh[s][j] *= rj;
+            }
             if (E > 0) {
 #pragma unroll
                 for (int s = 0; s < SE; ++s) st.Ah[s][j] *= rj;
             }
             // keep each column's LDS reads next to their FMAs (otherwise the scheduler may drift
             // the Ah chain away from the Gh chain and spill the Lq values in between)
+            if (C::PIN) {
+#pragma unroll
+                for (int s = 0; s < SE; ++s) pin(st.Ah[s][j]);
+                if (!C::PARK) {
+#pragma unroll
+                    for (int s = 0; s < SM; ++s) pin(st.Gh[s][j]);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    DQP_PHASE_FENCE();
     STAMP(P, 2);
 
 #pragma unroll
@@ -395,11 +485,22 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
             const double iu = frcp(uck);
             const double tauk = uck * uck * frcp(nrm2 - alpha * vk);
             double *tl = lds + C::oTl + C::toff(k);
+            if (C::PIN) {
+                // one exec-masked region with immediate LDS offsets (the select-an-address form below
+                // costs an address VGPR per element, and LLVM then keeps all of them for phase G)
 #pragma unroll
-            for (int c = 0; c < ck; ++c) {
-                u[c] *= iu;
-                double *dst = (r == 0) ? tl + c : dummy;
-                *dst = u[c];
+                for (int c = 0; c < ck; ++c) u[c] *= iu;
+                if (r == 0) {
+#pragma unroll
+                    for (int c = 0; c < ck; ++c) tl[c] = u[c];
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < ck; ++c) {
+                    u[c] *= iu;
+                    double *dst = (r == 0) ? tl + c : dummy;
+                    *dst = u[c];
+                }
             }
             if (r == lk) { st.tau[sk] = tauk; st.rdu1[sk] = frcp(alpha); }
             // rows of Ah above k
@@ -417,15 +518,25 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
             }
             if (r == lk) st.Ah[sk][ck] = alpha;
             // rows of Gh
+            if (!C::PARK) {
 #pragma unroll
-            for (int s = 0; s < SM; ++s) {
-                double w = st.Gh[s][ck];
+                for (int s = 0; s < SM; ++s) {
+                    double w = st.Gh[s][ck];
 #pragma unroll
-                for (int c = 0; c < ck; ++c) w = fma(st.Gh[s][c], u[c], w);
-                const double tw = tauk * w;
+                    for (int c = 0; c < ck; ++c) w = fma(st.Gh[s][c], u[c], w);
+                    const double tw = tauk * w;
 #pragma unroll
-                for (int c = 0; c < ck; ++c) st.Gh[s][c] = fma(-tw, u[c], st.Gh[s][c]);
-                st.Gh[s][ck] -= tw;
+                    for (int c = 0; c < ck; ++c) st.Gh[s][c] = fma(-tw, u[c], st.Gh[s][c]);
+                    st.Gh[s][ck] -= tw;
+                }
+            }
+            if (C::PIN) {           // next reflector's LDS traffic stays behind this one's arithmetic
+#pragma unroll
+                for (int s = 0; s < SE; ++s) pin(st.Ah[s][ck]);
+                if (!C::PARK) {
+#pragma unroll
+                    for (int s = 0; s < SM; ++s) pin(st.Gh[s][ck]);
+                }
             }
         }
 #ifdef DQP_STAMPS_C
@@ -433,6 +544,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
 #endif
         __syncthreads();          // tails are read back as distributed vectors
         __builtin_amdgcn_sched_barrier(0);
+        DQP_PHASE_FENCE();
 
         // D: xy = U^-1 b
         {
@@ -455,13 +567,63 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         }
     }
     __builtin_amdgcn_sched_barrier(0);
+    DQP_PHASE_FENCE();
+    if (C::PARK) {
+        // B, C for G on its own: Gh = G Lq^-T, then the reflectors (tails in LDS, read row-uniformly)
+        if (mpc) mpc_rows_G<SM, N>(P, M, st.Gh, r);
+        else load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
+        const double *Lp = relabel(lds + C::oLq);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+#pragma unroll
+            for (int k = 0; k < j; ++k) {
+                const double ljk = Lp[tri(j) + k];
+#pragma unroll
+                for (int s = 0; s < SM; ++s) st.Gh[s][j] = fma(-st.Gh[s][k], ljk, st.Gh[s][j]);
+            }
+            const double rj = BC(st.rdq, j);
+#pragma unroll
+            for (int s = 0; s < SM; ++s) { st.Gh[s][j] *= rj; pin(st.Gh[s][j]); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (E > 0) {
+#pragma unroll
+            for (int k = E - 1; k >= 0; --k) {
+                const int ck = R + k;
+                const double *tl = lds + C::oTl + C::toff(k);
+                const double tauk = BC(st.tau, k);
+                double w[SM];
+#pragma unroll
+                for (int s = 0; s < SM; ++s) w[s] = st.Gh[s][ck];
+#pragma unroll
+                for (int c = 0; c < ck; ++c) {
+                    const double uc = tl[c];
+#pragma unroll
+                    for (int s = 0; s < SM; ++s) w[s] = fma(st.Gh[s][c], uc, w[s]);
+                }
+#pragma unroll
+                for (int s = 0; s < SM; ++s) { w[s] *= tauk; st.Gh[s][ck] -= w[s]; }
+#pragma unroll
+                for (int c = 0; c < ck; ++c) {
+                    const double uc = tl[c];
+#pragma unroll
+                    for (int s = 0; s < SM; ++s) st.Gh[s][c] = fma(-w[s], uc, st.Gh[s][c]);
+                }
+#pragma unroll
+                for (int s = 0; s < SM; ++s) { pin(st.Gh[s][0]); pin(st.Gh[s][ck]); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    DQP_PHASE_FENCE();
     STAMP(P, 3);
 
     {   // E: ph = Lq^-1 p ; [cp ; py] = Qf^T ph
         double ph[SN];
 #pragma unroll
         for (int s = 0; s < SN; ++s) ph[s] = p0[s];
-        tri_solve<SN, N>(lds + C::oLq, st.rdq, ph, r);
+        tri_solve<SN, N>(C::PARK ? relabel(lds + C::oLq) : lds + C::oLq, st.rdq, ph, r);
         if (E > 0) {
             apply_QfT<C>(lds, st.tau, ph, r);
             shift_down<C>(ph, st.py, r);
@@ -493,8 +655,24 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         vec_put<SM>(lds + C::oHp, hp, M, r, dummy);
     }
     __builtin_amdgcn_sched_barrier(0);
+    DQP_PHASE_FENCE();
     STAMP(P, 4);
 
+    if (C::PARK && E > 0) {
+        // three register slots per N-space matrix: W and U leave the register file here (phase G
+        // needs the room for Lq Qf) and come back for the epilogue
+        park_GU<C>(P.workspace + qp * (long long)C::wsQP, st, r);
+#pragma unroll
+        for (int s = 0; s < SM; ++s)
+#pragma unroll
+            for (int e = 0; e < E; ++e) st.Gh[s][R + e] = 0.0;
+#pragma unroll
+        for (int s = 0; s < SE; ++s)
+#pragma unroll
+            for (int c = 0; c < N; ++c) st.Ah[s][c] = 0.0;
+        __builtin_amdgcn_sched_barrier(0);
+        DQP_PHASE_FENCE();
+    }
     {   // G: LqZ = (Lq Qf)[:, :R] ;  qv = (Lq Qf)[:, R:] w1
         double Ld[SN][N];
         const double *Lp = lds + C::oLq;
@@ -531,6 +709,10 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
 #pragma unroll
                     for (int s = 0; s < SN; ++s) Ld[s][c] = fma(-w[s], uc, Ld[s][c]);
                 }
+                if (C::PIN) {
+#pragma unroll
+                    for (int s = 0; s < SN; ++s) { pin(Ld[s][0]); pin(Ld[s][ck]); }
+                }
             }
         }
 #pragma unroll
@@ -551,6 +733,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         vec_put<SN>(lds + C::oQv, qv, N, r, dummy);
     }
     __builtin_amdgcn_sched_barrier(0);
+    DQP_PHASE_FENCE();
     STAMP(P, 5);
 
     // H: the reflector tails are done for now: park them in the caller's workspace (read back
@@ -559,26 +742,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         double *ws = P.workspace + qp * (long long)C::wsQP;
         for (int e = r; e < C::tailsz; e += 16) ws[C::wTl + e] = lds[C::oTl + e];
         for (int e = r; e < tri(N); e += 16) ws[C::wLq + e] = lds[C::oLq + e];
-#pragma unroll
-        for (int s = 0; s < SM; ++s) {
-            const int i = r + 16 * s;
-            if (i < M) {
-#pragma unroll
-                for (int c = 0; c < N; ++c) ws[C::wG + c * M + i] = st.Gh[s][c];   // column-major: the 16
-                // lanes of a QP write 16 consecutive doubles (row-major 8-byte stores 240 B apart
-                // cost 5x write amplification in HBM)
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < SE; ++s) {
-            const int k = r + 16 * s;
-            if (k < E) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) ws[C::wU + e * E + k] = st.Ah[s][R + e];
-                ws[C::wTau + k] = st.tau[s];
-                ws[C::wRdu + k] = st.rdu1[s];
-            }
-        }
+        if (!C::PARK) park_GU<C>(ws, st, r);
 #pragma unroll
         for (int s = 0; s < SN; ++s)
             if (r + 16 * s < N) ws[C::wRdq + r + 16 * s] = st.rdq[s];
@@ -616,6 +780,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         st.rdiag[s] = i < M ? v : 0.0;
     }
     __builtin_amdgcn_sched_barrier(0);
+    DQP_PHASE_FENCE();
 }
 
 // y = LqZ v + cc * qv   (N-space), returns sum of squares partial (lane-local)
@@ -851,6 +1016,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
 #pragma unroll
     for (int s = 0; s < SE; ++s) yv[s] = 0.0;
     if (E > 0) {
+        if (C::PARK) unpark_WU<C>(P.workspace + qp * (long long)C::wsQP, st, r);
         shift_up<C>(st.xy, xh, r);
         apply_Qf<C>(lds, st.tau, xh, r);
         double wz[SE];
