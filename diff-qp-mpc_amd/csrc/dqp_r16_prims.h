@@ -93,6 +93,15 @@ __device__ __forceinline__ double frsqrt(double d)
 #define DQP_STR2(x) #x
 #define DQP_STR(x) DQP_STR2(x)
 #define STAMP(P, i) asm volatile("; DQPMARK " DQP_STR(i))
+#elif defined(DQP_SETUP_STOP)   /* measurement builds (tools/setup_phases.py): the wavefront ends at phase boundary DQP_SETUP_STOP */
+#define STAMP(P, i)                                                                  \
+    do {                                                                             \
+        if ((i) == DQP_SETUP_STOP) {                                                 \
+            const double a__ = stop_sum<DQP_SETUP_STOP>(st);                         \
+            (P).zhat[qp * 2 + (r & 1)] = a__;                                        \
+            __builtin_amdgcn_endpgm();                                               \
+        }                                                                            \
+    } while (0)
 #elif !defined(DQP_STAMPS)
 #define STAMP(P, i) do { } while (0)
 #else

@@ -50,6 +50,16 @@ template <int N_, int M_, int E_> struct Cfg {
 #define DQP_R16N_PIN_ALL 1
 #endif
     static constexpr bool PIN = PARK || DQP_R16N_PIN_ALL;   // ordered setup (pin / exec-masked tail stores)
+#ifndef DQP_R16N_SPLIT_ALL
+#define DQP_R16N_SPLIT_ALL 0
+#endif
+    static constexpr bool SPLIT = PARK || DQP_R16N_SPLIT_ALL;   // A pass (B, C, D on Ah) before the G pass
+#ifndef DQP_R16N_EARLY_CTX
+#define DQP_R16N_EARLY_CTX 1
+#endif
+    // the factorisation context goes to the workspace piece by piece as each piece becomes final, so
+    // that its 16 KB per QP drain under the following phases instead of in one burst at the end
+    static constexpr bool EARLY = DQP_R16N_EARLY_CTX;
     // LDS per QP (doubles)
     static constexpr int tailsz = E_ * (N_ - E_) + E_ * (E_ - 1) / 2;     // sum_k c_k, c_k = R + k
     static constexpr int oLq = 0;                       // packed lower triangle of Lq
@@ -353,6 +363,46 @@ __device__ __forceinline__ void unpark_WU(const double *ws, State<C> &st, int r)
     }
 }
 
+#ifdef DQP_SETUP_STOP
+// keeps alive exactly what the setup has produced up to phase boundary K (registers; the LDS and
+// workspace writes are side effects already)
+template <int K, class C> __device__ __forceinline__ double stop_sum(const State<C> &st)
+{
+    double a = 0.0;
+#pragma unroll
+    for (int s = 0; s < C::SN; ++s) a += st.rdq[s];
+    if (K >= 2 || K == 0) {
+#pragma unroll
+        for (int s = 0; s < C::SM; ++s)
+#pragma unroll
+            for (int c = 0; c < C::N; ++c) a += st.Gh[s][c];
+#pragma unroll
+        for (int s = 0; s < C::SE; ++s)
+#pragma unroll
+            for (int c = 0; c < C::N; ++c) a += st.Ah[s][c];
+    }
+    if (K >= 3 || K == 0) {
+#pragma unroll
+        for (int s = 0; s < C::SE; ++s) a += st.tau[s] + st.rdu1[s] + st.xy[s];
+    }
+    if (K >= 4 || K == 0) {
+#pragma unroll
+        for (int s = 0; s < C::SE; ++s) a += st.py[s] + st.w1[s];
+    }
+    if (K >= 5 || K == 0) {
+#pragma unroll
+        for (int s = 0; s < C::SN; ++s)
+#pragma unroll
+            for (int c = 0; c < C::R; ++c) a += st.LqZ[s][c];
+    }
+    if (K >= 15) {
+#pragma unroll
+        for (int s = 0; s < C::SM; ++s) a += st.rdiag[s];
+    }
+    return a;
+}
+#endif
+
 // ------------------------------------------------------------------------------------------
 template <class C>
 __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, double *lds, State<C> &st)
@@ -401,6 +451,13 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         tri_store<SN, N>(lds + C::oLq, Lq, r, dummy);
     }
     __syncthreads();
+    if (C::EARLY) {
+        double *ws = P.workspace + qp * (long long)C::wsQP;
+        for (int e = r; e < tri(N); e += 16) ws[C::wLq + e] = lds[C::oLq + e];
+#pragma unroll
+        for (int s = 0; s < SN; ++s)
+            if (r + 16 * s < N) ws[C::wRdq + r + 16 * s] = st.rdq[s];
+    }
     __builtin_amdgcn_sched_barrier(0);
     DQP_PHASE_FENCE();
     STAMP(P, 1);
@@ -409,10 +466,10 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     // slots per N-space row (C::PARK) cannot hold Gh, Ah and a reflector at once: they do A first
     // (B, C, D on Ah alone), then G (B, then the reflectors re-read from LDS) -- see below.
     if (mpc) {
-        if (!C::PARK) mpc_rows_G<SM, N>(P, M, st.Gh, r);
+        if (!C::SPLIT) mpc_rows_G<SM, N>(P, M, st.Gh, r);
         if (E > 0) mpc_rows_A<SE, N>(P, qp, E, st.Ah, r);
     } else {
-        if (!C::PARK) load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
+        if (!C::SPLIT) load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
         if (E > 0) load_rows<SE, N>(P.A + qp * P.sA, E, st.Ah, r);
     }
     {
@@ -422,7 +479,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
 #pragma unroll
             for (int k = 0; k < j; ++k) {
                 const double ljk = Lp[tri(j) + k];
-                if (!C::PARK) {
+                if (!C::SPLIT) {
 #pragma unroll
                     for (int s = 0; s < SM; ++s) st.Gh[s][j] = fma(-st.Gh[s][k], ljk, st.Gh[s][j]);
                 }
@@ -432,7 +489,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
                 }
             }
             const double rj = BC(st.rdq, j);
-            if (!C::PARK) {
+            if (!C::SPLIT) {
 #pragma unroll
                 for (int s = 0; s < SM; ++s) st.Gh[s][j] *= rj;
             }
@@ -445,7 +502,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
             if (C::PIN) {
 #pragma unroll
                 for (int s = 0; s < SE; ++s) pin(st.Ah[s][j]);
-                if (!C::PARK) {
+                if (!C::SPLIT) {
 #pragma unroll
                     for (int s = 0; s < SM; ++s) pin(st.Gh[s][j]);
                 }
@@ -518,7 +575,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
             }
             if (r == lk) st.Ah[sk][ck] = alpha;
             // rows of Gh
-            if (!C::PARK) {
+            if (!C::SPLIT) {
 #pragma unroll
                 for (int s = 0; s < SM; ++s) {
                     double w = st.Gh[s][ck];
@@ -533,7 +590,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
             if (C::PIN) {           // next reflector's LDS traffic stays behind this one's arithmetic
 #pragma unroll
                 for (int s = 0; s < SE; ++s) pin(st.Ah[s][ck]);
-                if (!C::PARK) {
+                if (!C::SPLIT) {
 #pragma unroll
                     for (int s = 0; s < SM; ++s) pin(st.Gh[s][ck]);
                 }
@@ -544,6 +601,10 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
 #endif
         __syncthreads();          // tails are read back as distributed vectors
         __builtin_amdgcn_sched_barrier(0);
+        if (C::EARLY) {
+            double *ws = P.workspace + qp * (long long)C::wsQP;
+            for (int e = r; e < C::tailsz; e += 16) ws[C::wTl + e] = lds[C::oTl + e];
+        }
         DQP_PHASE_FENCE();
 
         // D: xy = U^-1 b
@@ -568,7 +629,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     }
     __builtin_amdgcn_sched_barrier(0);
     DQP_PHASE_FENCE();
-    if (C::PARK) {
+    if (C::SPLIT) {
         // B, C for G on its own: Gh = G Lq^-T, then the reflectors (tails in LDS, read row-uniformly)
         if (mpc) mpc_rows_G<SM, N>(P, M, st.Gh, r);
         else load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
@@ -623,7 +684,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         double ph[SN];
 #pragma unroll
         for (int s = 0; s < SN; ++s) ph[s] = p0[s];
-        tri_solve<SN, N>(C::PARK ? relabel(lds + C::oLq) : lds + C::oLq, st.rdq, ph, r);
+        tri_solve<SN, N>(C::SPLIT ? relabel(lds + C::oLq) : lds + C::oLq, st.rdq, ph, r);
         if (E > 0) {
             apply_QfT<C>(lds, st.tau, ph, r);
             shift_down<C>(ph, st.py, r);
@@ -658,6 +719,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     DQP_PHASE_FENCE();
     STAMP(P, 4);
 
+    if (C::EARLY && !C::PARK) park_GU<C>(P.workspace + qp * (long long)C::wsQP, st, r);
     if (C::PARK && E > 0) {
         // three register slots per N-space matrix: W and U leave the register file here (phase G
         // needs the room for Lq Qf) and come back for the epilogue
@@ -739,13 +801,15 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     // H: the reflector tails are done for now: park them in the caller's workspace (read back
     // for the epilogue), then Rm = Gz Gz^T goes, packed, into the same LDS region.
     {
-        double *ws = P.workspace + qp * (long long)C::wsQP;
-        for (int e = r; e < C::tailsz; e += 16) ws[C::wTl + e] = lds[C::oTl + e];
-        for (int e = r; e < tri(N); e += 16) ws[C::wLq + e] = lds[C::oLq + e];
-        if (!C::PARK) park_GU<C>(ws, st, r);
+        if (!C::EARLY) {
+            double *ws = P.workspace + qp * (long long)C::wsQP;
+            for (int e = r; e < C::tailsz; e += 16) ws[C::wTl + e] = lds[C::oTl + e];
+            for (int e = r; e < tri(N); e += 16) ws[C::wLq + e] = lds[C::oLq + e];
+            if (!C::PARK) park_GU<C>(ws, st, r);
 #pragma unroll
-        for (int s = 0; s < SN; ++s)
-            if (r + 16 * s < N) ws[C::wRdq + r + 16 * s] = st.rdq[s];
+            for (int s = 0; s < SN; ++s)
+                if (r + 16 * s < N) ws[C::wRdq + r + 16 * s] = st.rdq[s];
+        }
     }
     __syncthreads();
     {
