@@ -39,6 +39,10 @@ struct KParams {
     const double *mC, *mc, *mF, *mf, *mx0, *mul, *muu;     // time-major inputs (qp_wrapper layout)
     double *mdC, *mdc, *mdF, *mdf, *mdx0;                  // backward outputs
     int mn, mm, mT;
+    // batch rule, null-space kernels: improving iterates of pass 1 ([it][B][snapDim]) and the history
+    // as the finish pass reads it
+    double *snap;
+    const double *histIn;
 };
 
 constexpr int TERM_HDR = 8;   // int32 header words in front of the redo list
@@ -74,9 +78,9 @@ __device__ __forceinline__ void term_zero_acc(const KParams &P)
 }
 
 // batch rule replay + redo list (dqp_term.hip); 0 on success
-size_t term_bytes(int B, int maxIter);
+size_t term_bytes(int B, int maxIter, int snapDim);
 int term_decide(const KParams &P, void *term, void *stream);
-void term_bind_pass1(KParams &P, void *term);
+void term_bind_pass1(KParams &P, void *term, int snapDim);
 void term_bind_pass2(KParams &P, void *term);
 
 
@@ -92,6 +96,7 @@ int r16_backward(const KParams &P, void *stream);
 // r16n_workspace_doubles(N, M, E) doubles per QP in P.workspace (0: no instantiation).
 int r16n_forward(const KParams &P, void *stream);
 long long r16n_workspace_doubles(int N, int M, int E);
+int r16n_snapshot_doubles(int N, int M, int E);
 // backward restarted from the context r16n_forward left in P.workspace (DQP_FLAG_BACKWARD_CTX)
 int r16n_backward(const KParams &P, void *stream);
 

@@ -60,10 +60,17 @@ long long r16n_workspace_doubles(int N, int M, int E)
 #define X(n, m, e)                                                                          \
     if (N == n && M == m && E == e)                                                         \
         return (long long)e * (n - e) + (long long)e * (e - 1) / 2 + (long long)n * (n + 1) / 2 + \
-               (long long)m * n + (long long)e * e + 2 * e + n;   /* = r16n::Cfg::wsQP */
+               (long long)m * n + (long long)e * e + 5 * e + n + 1;   /* = r16n::Cfg::wsQP */
     DQP_R16N_SIZE_LIST
 #undef X
     return 0;
+}
+
+// doubles per (problem, iteration) of the iterate snapshots the null-space kernels keep for the batch
+// rule's finish pass (= r16n::Cfg::snapDim); 0 when the size has no null-space kernel
+int r16n_snapshot_doubles(int N, int M, int E)
+{
+    return r16n_workspace_doubles(N, M, E) > 0 ? (N - E) + 2 * M + 2 : 0;
 }
 
 }  // namespace dqp

@@ -770,7 +770,7 @@ __attribute__((visibility("default"))) size_t
 dqp_termination_bytes(const dqp_dims *d, const dqp_opts *o)
 {
     if (!d || d->nbatch <= 0 || !o || !(o->flags & DQP_FLAG_BATCH_TERMINATION)) return 0;
-    return dqp::term_bytes(d->nbatch, o->max_iter);
+    return dqp::term_bytes(d->nbatch, o->max_iter, dqp::r16n_snapshot_doubles(d->nz, d->nineq, d->neq));
 }
 
 static int forward_once(const KParams &P, size_t lds, void *workspace, void *stream);
@@ -801,7 +801,9 @@ dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, cons
     // Three enqueues on `stream`, no host synchronisation, hipGraph-capturable.
     if (!termination || P.maxIter < 1 || P.maxIter > 64) return DQP_ERR_BAD_ARG;
     P.eps = opts ? opts->eps : 1e-12;            // the batch rule uses the reference's eps itself
-    term_bind_pass1(P, termination);
+    // null-space kernels keep their improving iterates: pass 2 is then an epilogue, not a re-solve
+    const bool nullspace = workspace && !(P.flags & (DQP_FLAG_GENERIC_ONLY | DQP_FLAG_NO_NULLSPACE)) && !P.dynId;
+    term_bind_pass1(P, termination, nullspace ? r16n_snapshot_doubles(P.N, P.M, P.E) : 0);
     if ((rc = forward_once(P, lds, workspace, stream)) != DQP_OK) return rc;
     if (P.flags & DQP_FLAG_HISTORY_ONLY) return DQP_OK;
     if ((rc = term_decide(P, termination, stream)) != DQP_OK) return rc;
@@ -876,7 +878,7 @@ dqp_mpc_qp_forward(const dqp_mpc_dims *md, const dqp_opts *opts, const double *C
     if (!(P.flags & DQP_FLAG_BATCH_TERMINATION)) return r16n_forward(P, stream);
     if (!termination || P.maxIter < 1 || P.maxIter > 64) return DQP_ERR_BAD_ARG;
     P.eps = opts ? opts->eps : 1e-12;
-    term_bind_pass1(P, termination);
+    term_bind_pass1(P, termination, r16n_snapshot_doubles(P.N, P.M, P.E));
     if ((rc = r16n_forward(P, stream)) != DQP_OK) return rc;
     if (P.flags & DQP_FLAG_HISTORY_ONLY) return DQP_OK;
     if ((rc = term_decide(P, termination, stream)) != DQP_OK) return rc;

@@ -81,7 +81,10 @@ template <int N_, int M_, int E_> struct Cfg {
     // 1/diag(Lq)
     static constexpr int wTl = 0, wLq = tailsz, wG = wLq + tri(N_), wU = wG + M_ * N_;
     static constexpr int wTau = wU + E_ * E_, wRdu = wTau + E_, wRdq = wRdu + E_;
-    static constexpr int wsQP = wRdq + N_;
+    // what the batch-rule finish pass needs on top of the backward context: xy, py, w1 (E each), delta
+    static constexpr int wXy = wRdq + N_, wPy = wXy + E_, wW1 = wPy + E_, wDl = wW1 + E_;
+    static constexpr int wsQP = wDl + 1;
+    static constexpr int snapDim = (N_ - E_) + 2 * M_ + 2;      // w, s, z, c of an iterate (+ pad)
 };
 
 // Phase boundary for the compiler: LDS contents are to be re-read after this point.  Without it LLVM
@@ -720,6 +723,14 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     STAMP(P, 4);
 
     if (C::EARLY && !C::PARK) park_GU<C>(P.workspace + qp * (long long)C::wsQP, st, r);
+    if (E > 0) {
+        double *ws = P.workspace + qp * (long long)C::wsQP;
+#pragma unroll
+        for (int s = 0; s < SE; ++s) {
+            const int k = r + 16 * s;
+            if (k < E) { ws[C::wXy + k] = st.xy[s]; ws[C::wPy + k] = st.py[s]; ws[C::wW1 + k] = st.w1[s]; }
+        }
+    }
     if (C::PARK && E > 0) {
         // three register slots per N-space matrix: W and U leave the register file here (phase G
         // needs the room for Lq Qf) and come back for the epilogue
@@ -868,6 +879,69 @@ __device__ __forceinline__ double rx_norm2_partial(const State<C> &st, const dou
     return a;
 }
 
+// Back to the caller's coordinates from the best iterate parked in LDS (oBw, oBs, oBz):
+//   x = Lq^-T Qf [w* ; xy],  y = U^-T (c* delta w1 - xy - py - W^T z*);  writes zhat, lam, slack, nu,
+// info, best_resid.  Shared by the forward kernel and the batch rule's finish pass.
+template <class C>
+__device__ __forceinline__ void epilogue(const KParams &P, long long qp, int r, double *lds, State<C> &st,
+                                         double bestc, double delta, int iters, double best, bool live,
+                                         bool reload_tails)
+{
+    constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
+    constexpr int SN = C::SN, SM = C::SM, SE = C::SE, SR = C::SR;
+    bool inM[SM];
+#pragma unroll
+    for (int s = 0; s < SM; ++s) inM[s] = r + 16 * s < M;
+    // the reflector tails come back from the workspace into the (now idle) Gz Gz^T region
+    __syncthreads();
+    if (E > 0 && reload_tails) {
+        const double *ws = P.workspace + qp * (long long)C::wsQP + C::wTl;
+        for (int e = r; e < C::tailsz; e += 16) lds[C::oTl + e] = ws[e];
+    }
+    __syncthreads();
+
+    // recover x = Lq^-T Qf [w* ; xy],  y = U^-T (c* delta w1 - xy - py - W^T z*)
+    double bw[SR], bs[SM], bz[SM];
+    vec_get<SR>(lds + C::oBw, bw, R, r);
+    vec_get<SM>(lds + C::oBs, bs, M, r);
+    vec_get<SM>(lds + C::oBz, bz, M, r);
+    double xh[SN];
+#pragma unroll
+    for (int s = 0; s < SN; ++s) xh[s] = (s < SR && r + 16 * s < R) ? bw[s < SR ? s : 0] : 0.0;
+    double yv[SE];
+#pragma unroll
+    for (int s = 0; s < SE; ++s) yv[s] = 0.0;
+    if (E > 0) {
+        if (C::PARK) unpark_WU<C>(P.workspace + qp * (long long)C::wsQP, st, r);
+        shift_up<C>(st.xy, xh, r);
+        apply_Qf<C>(lds, st.tau, xh, r);
+        double wz[SE];
+        mul_WT<C>(st, bz, wz, r);
+#pragma unroll
+        for (int s = 0; s < SE; ++s)
+            yv[s] = (r + 16 * s < E) ? bestc * delta * st.w1[s] - st.xy[s] - st.py[s] - wz[s] : 0.0;
+        solve_UT<C>(st, yv, r);
+    }
+    tri_solve_T<SN, N>(lds + C::oLq, st.rdq, xh, r);
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < SN; ++s)
+            if (r + 16 * s < N) P.zhat[qp * N + r + 16 * s] = xh[s];
+#pragma unroll
+        for (int s = 0; s < SM; ++s)
+            if (inM[s]) { P.lam[qp * M + r + 16 * s] = bz[s]; P.slack[qp * M + r + 16 * s] = bs[s]; }
+        if (E > 0) {
+#pragma unroll
+            for (int s = 0; s < SE; ++s)
+                if (r + 16 * s < E) P.nu[qp * E + r + 16 * s] = yv[s];
+        }
+        if (r == 0) {
+            if (P.info) { P.info[2 * qp] = st.status; P.info[2 * qp + 1] = iters; }
+            if (P.best_resid) P.best_resid[qp] = best;
+        }
+    }
+}
+
 template <class C>
 __global__ __launch_bounds__(64) void forward_kernel(KParams P)
 {
@@ -934,6 +1008,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             if (mz < 0.0 && inM[s]) z[s] -= mz - 1.0;
         }
         delta = mz < 0.0 ? 1.0 - mz : 0.0;        // rho_0 = delta * W^T 1
+        if (r == 0) P.workspace[qp * (long long)C::wsQP + C::wDl] = delta;
     }
 
     // gz = Gz^T z is carried incrementally (updated with the step's own transposed product)
@@ -972,6 +1047,16 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
                 vec_put<SR>(lds + C::oBw, w, R, r, dummy);
                 vec_put<SM>(lds + C::oBs, s_, M, r, dummy);
                 vec_put<SM>(lds + C::oBz, z, M, r, dummy);
+                if (P.snap && live) {        // batch rule: the finish pass picks the best iterate up to I*
+                    double *sp = P.snap + ((long long)it * P.B + qp) * C::snapDim;
+#pragma unroll
+                    for (int s = 0; s < SR; ++s)
+                        if (inR[s]) sp[r + 16 * s] = w[s];
+#pragma unroll
+                    for (int s = 0; s < SM; ++s)
+                        if (inM[s]) { sp[R + r + 16 * s] = s_[s]; sp[R + M + r + 16 * s] = z[s]; }
+                    if (r == 0) sp[R + 2 * M] = cc;
+                }
             } else {
                 nNot += 1;
             }
@@ -1060,78 +1145,17 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     STAMP(P, 7);
 
     if (P.hist && r == 0 && live) hist_fill(P, qp, iters);
-    // the reflector tails come back from the workspace into the (now idle) Gz Gz^T region
-    __syncthreads();
-    if (E > 0) {
-        const double *ws = P.workspace + qp * (long long)C::wsQP + C::wTl;
-        for (int e = r; e < C::tailsz; e += 16) lds[C::oTl + e] = ws[e];
-    }
-    __syncthreads();
-
-    // recover x = Lq^-T Qf [w* ; xy],  y = U^-T (c* delta w1 - xy - py - W^T z*)
-    double bw[SR], bs[SM], bz[SM];
-    vec_get<SR>(lds + C::oBw, bw, R, r);
-    vec_get<SM>(lds + C::oBs, bs, M, r);
-    vec_get<SM>(lds + C::oBz, bz, M, r);
-    double xh[SN];
-#pragma unroll
-    for (int s = 0; s < SN; ++s) xh[s] = (s < SR && r + 16 * s < R) ? bw[s < SR ? s : 0] : 0.0;
-    double yv[SE];
-#pragma unroll
-    for (int s = 0; s < SE; ++s) yv[s] = 0.0;
-    if (E > 0) {
-        if (C::PARK) unpark_WU<C>(P.workspace + qp * (long long)C::wsQP, st, r);
-        shift_up<C>(st.xy, xh, r);
-        apply_Qf<C>(lds, st.tau, xh, r);
-        double wz[SE];
-        mul_WT<C>(st, bz, wz, r);
-#pragma unroll
-        for (int s = 0; s < SE; ++s)
-            yv[s] = (r + 16 * s < E) ? bestc * delta * st.w1[s] - st.xy[s] - st.py[s] - wz[s] : 0.0;
-        solve_UT<C>(st, yv, r);
-    }
-    tri_solve_T<SN, N>(lds + C::oLq, st.rdq, xh, r);
-    if (live) {
-#pragma unroll
-        for (int s = 0; s < SN; ++s)
-            if (r + 16 * s < N) P.zhat[qp * N + r + 16 * s] = xh[s];
-#pragma unroll
-        for (int s = 0; s < SM; ++s)
-            if (inM[s]) { P.lam[qp * M + r + 16 * s] = bz[s]; P.slack[qp * M + r + 16 * s] = bs[s]; }
-        if (E > 0) {
-#pragma unroll
-            for (int s = 0; s < SE; ++s)
-                if (r + 16 * s < E) P.nu[qp * E + r + 16 * s] = yv[s];
-        }
-        if (r == 0) {
-            if (P.info) { P.info[2 * qp] = st.status; P.info[2 * qp + 1] = iters; }
-            if (P.best_resid) P.best_resid[qp] = best;
-        }
-    }
+    epilogue<C>(P, qp, r, lds, st, bestc, delta, iters, best, live, true);
     STAMP(P, 14);
 }
 
-// Backward pass in the same null-space coordinates (reference: qp.py:128-183 = factor_kkt +
-// solve_kkt with rhs (dl_dzhat, 0, 0, 0) + the outer-product gradient formulas).  With
-// gq = Qf^T Lq^-1 g split into its null-space part gz and range part gy:
-//   (Gz Gz^T + diag(s/lam)) dlam = -Gz gz,   dw = -(gz + Gz^T dlam),   dx = Lq^-T Qf [dw ; 0],
-//   dnu = -U^-T (gy + W^T dlam).
-// Nothing is refactored: Lq, the reflectors, [Gz | W] and U come back from the workspace the
-// forward kernel of the same (Q, G, A) filled (DQP_FLAG_BACKWARD_CTX), like the reference's
-// ctx.Q_LU / S_LU / R; T is accumulated straight into registers.
+// The factorisation context a forward launch left in the workspace -> LDS (Lq, reflector tails) and
+// registers ([Gz | W], U, tau, 1/diag(U), 1/diag(Lq)).
 template <class C>
-__global__ __launch_bounds__(64) void backward_kernel(KParams P)
+__device__ __forceinline__ void load_ctx(const KParams &P, long long qp, int r, double *lds, State<C> &st)
 {
     constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
-    constexpr int SN = C::SN, SM = C::SM, SE = C::SE, SR = C::SR;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
-    long long qp = (long long)blockIdx.x * 4 + qrow;
-    const bool live = qp < P.B;
-    if (!live) qp = P.B - 1;
-    double *lds = sm + qrow * C::ldsQPpad;
-
-    State<C> st;
+    constexpr int SN = C::SN, SM = C::SM, SE = C::SE;
     st.status = DQP_STATUS_OK;
     {
         const double *ws = P.workspace + qp * (long long)C::wsQP;
@@ -1167,6 +1191,88 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P)
             st.rdq[s] = i < N ? v : 0.0;
         }
     }
+}
+
+// Pass 2 of the batch-coupled rule when pass 1 kept its improving iterates (P.snap): nothing is
+// solved again.  A flagged problem (its best iterate came at or after the batch's stop I*) takes the
+// best of its iterates before I* from the snapshots, the factorisation context from the workspace,
+// and runs the epilogue only.
+template <class C>
+__global__ __launch_bounds__(64) void finish_kernel(KParams P)
+{
+    constexpr int M = C::M, E = C::E, R = C::R;
+    constexpr int SM = C::SM, SE = C::SE, SR = C::SR;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
+    long long qp = (long long)blockIdx.x * 4 + qrow;
+    bool live = qp < P.B;
+    if (!live) qp = P.B - 1;
+    live = live && P.cap[TERM_HDR + qp] != 0;
+    if (__builtin_amdgcn_ballot_w64(live) == 0) return;
+    const int cap = min(P.maxIter, P.cap[0]);
+    double *lds = sm + qrow * C::ldsQPpad;
+    double *dummy = lds + C::oDummy + r;
+    State<C> st;
+    load_ctx<C>(P, qp, r, lds, st);
+    const double *ws = P.workspace + qp * (long long)C::wsQP;
+#pragma unroll
+    for (int s = 0; s < SE; ++s) {
+        const int k = r + 16 * s, kc = k < E ? k : (E > 0 ? E - 1 : 0);
+        const double a = ws[C::wXy + kc], b = ws[C::wPy + kc], c = ws[C::wW1 + kc];
+        st.xy[s] = (E > 0 && k < E) ? a : 0.0;
+        st.py[s] = (E > 0 && k < E) ? b : 0.0;
+        st.w1[s] = (E > 0 && k < E) ? c : 0.0;
+    }
+    const double delta = ws[C::wDl];
+    // the problem's best iteration before the stop (same rule as the kernels: first strict minimum)
+    const double2 *h = reinterpret_cast<const double2 *>(P.histIn) + qp;
+    double best = h[0].x;
+    int arg = 0;
+    for (int it = 1; it < cap; ++it) {
+        const double v = h[(long long)it * P.B].x;
+        if (v < best) { best = v; arg = it; }
+    }
+    const double *sp = P.snap + ((long long)arg * P.B + qp) * C::snapDim;
+    double bw[SR], bs[SM], bz[SM];
+#pragma unroll
+    for (int s = 0; s < SR; ++s) { const int i = r + 16 * s; const double v = sp[i < R ? i : 0]; bw[s] = i < R ? v : 0.0; }
+#pragma unroll
+    for (int s = 0; s < SM; ++s) {
+        const int i = r + 16 * s, ic = i < M ? i : 0;
+        const double a = sp[R + ic], b = sp[R + M + ic];
+        bs[s] = i < M ? a : 0.0;
+        bz[s] = i < M ? b : 0.0;
+    }
+    const double bestc = sp[R + 2 * M];
+    vec_put<SR>(lds + C::oBw, bw, R, r, dummy);
+    vec_put<SM>(lds + C::oBs, bs, M, r, dummy);
+    vec_put<SM>(lds + C::oBz, bz, M, r, dummy);
+    st.status = P.info ? P.info[2 * qp] : DQP_STATUS_OK;       // pass 1's status stands
+    epilogue<C>(P, qp, r, lds, st, bestc, delta, cap, best, live, false);
+}
+
+// Backward pass in the same null-space coordinates (reference: qp.py:128-183 = factor_kkt +
+// solve_kkt with rhs (dl_dzhat, 0, 0, 0) + the outer-product gradient formulas).  With
+// gq = Qf^T Lq^-1 g split into its null-space part gz and range part gy:
+//   (Gz Gz^T + diag(s/lam)) dlam = -Gz gz,   dw = -(gz + Gz^T dlam),   dx = Lq^-T Qf [dw ; 0],
+//   dnu = -U^-T (gy + W^T dlam).
+// Nothing is refactored: Lq, the reflectors, [Gz | W] and U come back from the workspace the
+// forward kernel of the same (Q, G, A) filled (DQP_FLAG_BACKWARD_CTX), like the reference's
+// ctx.Q_LU / S_LU / R; T is accumulated straight into registers.
+template <class C>
+__global__ __launch_bounds__(64) void backward_kernel(KParams P)
+{
+    constexpr int N = C::N, M = C::M, E = C::E, R = C::R;
+    constexpr int SN = C::SN, SM = C::SM, SE = C::SE, SR = C::SR;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int lane = threadIdx.x, r = lane & 15, qrow = lane >> 4;
+    long long qp = (long long)blockIdx.x * 4 + qrow;
+    const bool live = qp < P.B;
+    if (!live) qp = P.B - 1;
+    double *lds = sm + qrow * C::ldsQPpad;
+
+    State<C> st;
+    load_ctx<C>(P, qp, r, lds, st);
     __syncthreads();
 
     bool inN[SN], inM[SM], inE[SE];
@@ -1373,6 +1479,7 @@ int launch(K kernel, const KParams &P, void *stream)
 int DQP_CAT(r16n_forward_, DQP_R16_N, DQP_R16_M, DQP_R16_E)(const KParams &P, void *stream)
 {
     using C = r16n::Cfg<DQP_R16_N, DQP_R16_M, DQP_R16_E>;
+    if (P.cap && P.snap && P.histIn) return r16n::launch<C>(r16n::finish_kernel<C>, P, stream);
     return r16n::launch<C>(r16n::forward_kernel<C>, P, stream);
 }
 #else

@@ -14,7 +14,9 @@
 // Buffer layout (dqp_termination_bytes): hist (maxIter, B) x {resid, mu} doubles | accumulators:
 // three u64 masks (improved, notbelow, notabove: one bit per iteration) | int32 header[TERM_HDR]
 // (header[0] = I*, header[1] = number of problems to redo, header[2] = block arrival counter) then
-// int32 redo[B] (the scan stores the problem's best iteration there, its last block the flag).
+// int32 redo[B] (the scan stores the problem's best iteration there, its last block the flag), then
+// (16-byte aligned) the iterate snapshots [maxIter][B][snapDim] of the null-space kernels: every
+// improving iterate of pass 1, so that pass 2 is an epilogue (r16n::finish_kernel), not a re-solve.
 // Pass 1 zeroes accumulators + header itself (term_zero_acc), so a forward call is three launches.
 #include "dqp_common.h"
 
@@ -111,25 +113,34 @@ __global__ __launch_bounds__(256) void term_scan_kernel(const double2 *hist, Acc
 inline Acc *acc_of(void *term, int B, int maxIter) { return (Acc *)((char *)term + hist_bytes(B, maxIter)); }
 inline int32_t *hdr_of(void *term, int B, int maxIter) { return (int32_t *)((char *)acc_of(term, B, maxIter) + sizeof(Acc)); }
 
-}  // namespace
-
-size_t term_bytes(int B, int maxIter)
+inline size_t snap_offset(int B, int maxIter)
 {
-    if (B <= 0 || maxIter <= 0) return 0;
-    return hist_bytes(B, maxIter) + sizeof(Acc) + (size_t)(TERM_HDR + B) * sizeof(int32_t);
+    const size_t o = hist_bytes(B, maxIter) + sizeof(Acc) + (size_t)(TERM_HDR + B) * sizeof(int32_t);
+    return (o + 15) & ~(size_t)15;
 }
 
-void term_bind_pass1(KParams &P, void *term)
+}  // namespace
+
+size_t term_bytes(int B, int maxIter, int snapDim)
+{
+    if (B <= 0 || maxIter <= 0) return 0;
+    return snap_offset(B, maxIter) + (size_t)B * maxIter * (snapDim > 0 ? snapDim : 0) * sizeof(double);
+}
+
+void term_bind_pass1(KParams &P, void *term, int snapDim)
 {
     P.hist = (double *)term;
     P.histIters = P.maxIter;
     P.cap = nullptr;
+    P.histIn = nullptr;
+    P.snap = snapDim > 0 ? (double *)((char *)term + snap_offset(P.B, P.maxIter)) : nullptr;
 }
 
 void term_bind_pass2(KParams &P, void *term)
 {
     P.hist = nullptr;
-    P.cap = hdr_of(term, P.B, P.maxIter);
+    P.histIn = (const double *)term;
+    P.cap = hdr_of(term, P.B, P.maxIter);         // P.snap stays as pass 1 had it
 }
 
 int term_decide(const KParams &P, void *term, void *stream)

@@ -63,7 +63,10 @@ enum {
                                       reference's rule (no sample improved for not_improved_lim
                                       iterations | best_resids.max() < eps | mu.min() > 1e32) to
                                       find the iteration the reference stops at, and the problems
-                                      whose best iterate came later are re-solved up to there.  Needs
+                                      whose best iterate came later are taken back to there: the
+                                      null-space kernels keep every improving iterate of pass 1 in
+                                      `termination` and finish from the right one (an epilogue, no
+                                      second solve); the other kernels re-solve up to there.  Needs
                                       the `termination` buffer (dqp_termination_bytes).  Without the
                                       flag a problem stops on its own (see dqp_qp_forward).        */
 #define DQP_FLAG_HISTORY_ONLY 32u   /* with DQP_FLAG_BATCH_TERMINATION: stop after pass 1 (every problem
@@ -112,13 +115,16 @@ const char *dqp_error_string(int code);
  * LDS/registers.  With it, the size-specialised forward kernels eliminate the equality
  * constraints once (null-space form), park the elimination's reflectors there between setup and
  * the final back-transformation -- ~1.4x faster at the metric size, same iterates in exact
- * arithmetic -- and leave the factorisation context (Lq, reflectors, [Gz | W], U; ~16 KB per QP at
- * the metric size) for dqp_qp_backward: pass the same buffer with DQP_FLAG_BACKWARD_CTX to skip
+ * arithmetic -- and leave the factorisation context (Lq, reflectors, [Gz | W], U, and the particular
+ * solution of the equality rows; ~16 KB per QP at the metric size) for dqp_qp_backward and for the
+ * finish pass of the batch rule: pass the same buffer with DQP_FLAG_BACKWARD_CTX to skip
  * the refactorisation (2x faster backward).  Without that flag backward needs no workspace. */
 size_t dqp_workspace_bytes(const dqp_dims *dims);
 
 /* Bytes of the device buffer DQP_FLAG_BATCH_TERMINATION needs (per-iteration residual history,
- * the batch reduction's accumulators and the redo list); 0 without the flag.  max_iter <= 64. */
+ * the batch reduction's accumulators, the redo list and -- sizes served by the null-space kernels --
+ * max_iter iterate snapshots of (nz - neq) + 2 nineq + 2 doubles per problem: 12 KB per QP at the
+ * metric size); 0 without the flag.  max_iter <= 64. */
 size_t dqp_termination_bytes(const dqp_dims *dims, const dqp_opts *opts);
 
 /*

@@ -303,7 +303,9 @@ def test_workspace_is_optional(dqp):
     Q, p, G, h, A, b = [dev(g["in_" + k], grad=False) for k in "QpGhAb"]
     B, nz, nineq, neq = 8, 30, 30, 15
     dims = _lib.dqp_dims(B, nz, nineq, neq, nz * nz, nz, nineq * nz, nineq, neq * nz, neq)
-    per_qp = (15 * 15 + 15 * 14 // 2) + 30 * 31 // 2 + 30 * 30 + 15 * 15 + 2 * 15 + 30
+    # tails, packed Lq, [Gz | W], U, tau + 1/diag(U), 1/diag(Lq), then xy / py / w1 and delta for the
+    # batch rule's finish pass
+    per_qp = (15 * 15 + 15 * 14 // 2) + 30 * 31 // 2 + 30 * 30 + 15 * 15 + 2 * 15 + 30 + 3 * 15 + 1
     assert lib.dqp_workspace_bytes(ctypes.byref(dims)) == B * per_qp * 8
     odd = _lib.dqp_dims(B, 7, 5, 2, 49, 7, 35, 5, 14, 2)
     assert lib.dqp_workspace_bytes(ctypes.byref(odd)) == 0         # generic kernels: no scratch
