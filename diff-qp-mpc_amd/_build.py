@@ -30,7 +30,8 @@ R16N_SIZES = [s for s in R16_SIZES if s[2] > 0] + [
     (35, 10, 30),   # n=6 m=1 T=5  (cartpole-2)
 ]
 
-PLAIN_SOURCES = ["dqp_pdipm.hip", "dqp_mpc.hip", "dqp_al.hip", "dqp_term.hip", "dqp_dyn.hip", "dqp_al_banded.hip"]
+PLAIN_SOURCES = ["dqp_pdipm.hip", "dqp_mpc.hip", "dqp_al.hip", "dqp_term.hip", "dqp_dyn.hip", "dqp_al_banded.hip",
+                 "dqp_ric.hip"]
 SOURCES = PLAIN_SOURCES + ["dqp_r16.hip", "dqp_r16n.hip", "dqp_dispatch.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-mllvm", "-pragma-unroll-threshold=10000000", "-mllvm", "-unroll-threshold=10000000"]

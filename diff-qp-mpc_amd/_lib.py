@@ -110,7 +110,7 @@ def load():
     lib.dqp_mpc_qp_forward.restype = ctypes.c_int
     lib.dqp_mpc_qp_forward.argtypes = [ctypes.POINTER(dqp_mpc_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 16
     lib.dqp_mpc_qp_backward.restype = ctypes.c_int
-    lib.dqp_mpc_qp_backward.argtypes = [ctypes.POINTER(dqp_mpc_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 13
+    lib.dqp_mpc_qp_backward.argtypes = [ctypes.POINTER(dqp_mpc_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 15
     lib.dqp_mpc_line_search.restype = ctypes.c_int
     lib.dqp_mpc_line_search.argtypes = ([ctypes.POINTER(dqp_mpc_dims), ctypes.c_int, ctypes.c_double] + [_dp] * 8 +
                                         [ctypes.c_double, ctypes.c_int32] + [_dp] * 5)

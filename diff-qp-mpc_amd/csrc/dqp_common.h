@@ -97,6 +97,11 @@ int r16_backward(const KParams &P, void *stream);
 int r16n_forward(const KParams &P, void *stream);
 long long r16n_workspace_doubles(int N, int M, int E);
 int r16n_snapshot_doubles(int N, int M, int E);
+// stage-wise (Riccati) PDIPM for MPC-structured QPs of any horizon (dqp_ric.hip): n + m <= 16
+bool ric_supported(int n_state, int n_ctrl);
+long long ric_workspace_doubles(int n_state, int n_ctrl, int T);
+int ric_forward(const KParams &P, void *stream);      // 1: no kernel for this (n, m)
+int ric_backward(const KParams &P, void *stream);
 // backward restarted from the context r16n_forward left in P.workspace (DQP_FLAG_BACKWARD_CTX)
 int r16n_backward(const KParams &P, void *stream);
 

@@ -668,6 +668,16 @@ __global__ __launch_bounds__(WAVE) void qp_backward_kernel(KParams P)
     if (lane == 0 && P.info) { P.info[2 * qp] = status; P.info[2 * qp + 1] = 0; }
 }
 
+void fill_opts(const dqp_opts *o, KParams &P)
+{
+    P.eps = (o ? o->eps : 1e-12) * 0.1;
+    P.stallTol = o ? o->stall_tol : 1e-10;
+    P.maxIter = o ? o->max_iter : 20;
+    P.notImprovedLim = o ? o->not_improved_lim : 3;
+    P.flags = o ? o->flags : 0u;
+    P.hist = nullptr; P.cap = nullptr; P.histIters = P.maxIter;
+}
+
 int fill_params(const dqp_dims *d, const dqp_opts *o, KParams &P, size_t &lds_bytes)
 {
 #ifdef DQP_STAMPS
@@ -689,12 +699,7 @@ int fill_params(const dqp_dims *d, const dqp_opts *o, KParams &P, size_t &lds_by
     // and moved the gradients of weakly active constraints (lam ~ 1e-4) by up to 1e-3 relative
     // (tools/stress_parity.py: 58 tolerance exceedances in 147k QPs -> 10 with the extra decade,
     // the same as never stopping at eps at all; costs ~1 iteration on average).
-    P.eps = (o ? o->eps : 1e-12) * 0.1;
-    P.stallTol = o ? o->stall_tol : 1e-10;
-    P.maxIter = o ? o->max_iter : 20;
-    P.notImprovedLim = o ? o->not_improved_lim : 3;
-    P.flags = o ? o->flags : 0u;
-    P.hist = nullptr; P.cap = nullptr; P.histIters = P.maxIter;
+    fill_opts(o, P);
     P.dynId = o ? o->dyn_id : 0;
     P.dynT = 0; P.dynN = 0; P.dynM = 0; P.dynDt = 0.0; P.dynX0 = nullptr;
     if (P.dynId) {
@@ -829,34 +834,60 @@ static int forward_once(const KParams &P, size_t lds, void *workspace, void *str
 
 // MPC-structured entry points: the null-space kernels assemble (Q,p,G,h,A,b) in registers from the
 // time-major MPC data and scatter the gradients back the same way -- no dense QP in HBM.
-static int mpc_params(const dqp_mpc_dims *md, const dqp_opts *opts, KParams &P, size_t &lds)
+// Which kernels serve an MPC shape: the dense null-space kernels where the QP size has an
+// instantiation (small horizons: one QP in registers), else the stage-wise Riccati kernels
+// (dqp_ric.hip: any horizon, n + m <= 16).
+enum { MPC_NONE = 0, MPC_R16N = 1, MPC_RIC = 2 };
+
+static int mpc_params(const dqp_mpc_dims *md, const dqp_opts *opts, KParams &P, size_t &lds, int &kind)
 {
-    if (!md || md->T < 2 || md->n_state < 1 || md->n_ctrl < 1 || !md->has_bounds) return DQP_ERR_BAD_ARG;
+    kind = MPC_NONE;
+    if (!md || md->T < 2 || md->n_state < 1 || md->n_ctrl < 1 || !md->has_bounds || md->nbatch < 0) return DQP_ERR_BAD_ARG;
     dqp_dims d = {};
     d.nbatch = md->nbatch;
     d.nz = md->T * (md->n_state + md->n_ctrl);
     d.nineq = 2 * md->T * md->n_ctrl;
     d.neq = md->T * md->n_state;
-    int rc = fill_params(&d, opts, P, lds);
-    if (rc != DQP_OK) return rc;
-    if (P.dynId) return DQP_ERR_BAD_ARG;
+    if (r16n_workspace_doubles(d.nz, d.nineq, d.neq) > 0) {
+        int rc = fill_params(&d, opts, P, lds);
+        if (rc != DQP_OK) return rc;
+        if (P.dynId) return DQP_ERR_BAD_ARG;
+        kind = MPC_R16N;
+    } else if (ric_supported(md->n_state, md->n_ctrl)) {
+        if (opts && opts->dyn_id) return DQP_ERR_BAD_ARG;
+        P.stamps = nullptr;
+        P.B = d.nbatch; P.N = d.nz; P.M = d.nineq; P.E = d.neq;
+        fill_opts(opts, P);
+        kind = MPC_RIC;
+    } else {
+        return DQP_ERR_TOO_LARGE;
+    }
     P.mn = md->n_state; P.mm = md->n_ctrl; P.mT = md->T;
-    return r16n_workspace_doubles(P.N, P.M, P.E) > 0 ? DQP_OK : DQP_ERR_TOO_LARGE;
+    return DQP_OK;
+}
+
+static size_t mpc_workspace_doubles(const KParams &P, int kind)
+{
+    if (kind == MPC_R16N) return (size_t)P.B * (size_t)r16n_workspace_doubles(P.N, P.M, P.E);
+    // four problems per wavefront, padding rows own a slot too
+    return (size_t)((P.B + 3) / 4 * 4) * (size_t)ric_workspace_doubles(P.mn, P.mm, P.mT);
 }
 
 __attribute__((visibility("default"))) int dqp_mpc_qp_supported(const dqp_mpc_dims *md)
 {
     KParams P = {};
     size_t lds = 0;
-    return mpc_params(md, nullptr, P, lds) == DQP_OK ? 1 : 0;
+    int kind;
+    return mpc_params(md, nullptr, P, lds, kind) == DQP_OK ? 1 : 0;
 }
 
 __attribute__((visibility("default"))) size_t dqp_mpc_qp_workspace_bytes(const dqp_mpc_dims *md)
 {
     KParams P = {};
     size_t lds = 0;
-    if (mpc_params(md, nullptr, P, lds) != DQP_OK || md->nbatch <= 0) return 0;
-    return (size_t)md->nbatch * (size_t)r16n_workspace_doubles(P.N, P.M, P.E) * sizeof(double);
+    int kind;
+    if (mpc_params(md, nullptr, P, lds, kind) != DQP_OK || md->nbatch <= 0) return 0;
+    return mpc_workspace_doubles(P, kind) * sizeof(double);
 }
 
 __attribute__((visibility("default"))) int
@@ -867,33 +898,38 @@ dqp_mpc_qp_forward(const dqp_mpc_dims *md, const dqp_opts *opts, const double *C
 {
     KParams P = {};
     size_t lds = 0;
-    int rc = mpc_params(md, opts, P, lds);
+    int kind;
+    int rc = mpc_params(md, opts, P, lds, kind);
     if (rc != DQP_OK) return rc;
     if (P.B == 0) return DQP_OK;
     if (!C || !c || !F || !f || !x0 || !u_lower || !u_upper || !tau || !lam || !nu || !slack || !workspace)
         return DQP_ERR_BAD_ARG;
+    auto run = [&](const KParams &Q) { return kind == MPC_R16N ? r16n_forward(Q, stream) : ric_forward(Q, stream); };
     P.mC = C; P.mc = c; P.mF = F; P.mf = f; P.mx0 = x0; P.mul = u_lower; P.muu = u_upper;
     P.zhat = tau; P.lam = lam; P.nu = nu; P.slack = slack; P.info = info; P.best_resid = best_resid;
     P.workspace = (double *)workspace;
-    if (!(P.flags & DQP_FLAG_BATCH_TERMINATION)) return r16n_forward(P, stream);
-    if (!termination || P.maxIter < 1 || P.maxIter > 64) return DQP_ERR_BAD_ARG;
+    if (P.maxIter < 1) return DQP_ERR_BAD_ARG;
+    if (!(P.flags & DQP_FLAG_BATCH_TERMINATION)) return run(P);
+    if (!termination || P.maxIter > 64) return DQP_ERR_BAD_ARG;
     P.eps = opts ? opts->eps : 1e-12;
-    term_bind_pass1(P, termination, r16n_snapshot_doubles(P.N, P.M, P.E));
-    if ((rc = r16n_forward(P, stream)) != DQP_OK) return rc;
+    term_bind_pass1(P, termination, kind == MPC_R16N ? r16n_snapshot_doubles(P.N, P.M, P.E) : 0);
+    if ((rc = run(P)) != DQP_OK) return rc;
     if (P.flags & DQP_FLAG_HISTORY_ONLY) return DQP_OK;
     if ((rc = term_decide(P, termination, stream)) != DQP_OK) return rc;
     term_bind_pass2(P, termination);
-    return r16n_forward(P, stream);
+    return run(P);
 }
 
 __attribute__((visibility("default"))) int
-dqp_mpc_qp_backward(const dqp_mpc_dims *md, const dqp_opts *opts, const double *tau, const double *lam,
-                    const double *nu, const double *slack, const double *dl_dtau, double *dC, double *dc,
-                    double *dF, double *df, double *dx0, int32_t *info, void *workspace, void *stream)
+dqp_mpc_qp_backward(const dqp_mpc_dims *md, const dqp_opts *opts, const double *C, const double *F,
+                    const double *tau, const double *lam, const double *nu, const double *slack,
+                    const double *dl_dtau, double *dC, double *dc, double *dF, double *df, double *dx0,
+                    int32_t *info, void *workspace, void *stream)
 {
     KParams P = {};
     size_t lds = 0;
-    int rc = mpc_params(md, opts, P, lds);
+    int kind;
+    int rc = mpc_params(md, opts, P, lds, kind);
     if (rc != DQP_OK) return rc;
     if (P.B == 0) return DQP_OK;
     if (!tau || !lam || !nu || !slack || !dl_dtau || !workspace) return DQP_ERR_BAD_ARG;
@@ -902,7 +938,10 @@ dqp_mpc_qp_backward(const dqp_mpc_dims *md, const dqp_opts *opts, const double *
     P.mdC = dC; P.mdc = dc; P.mdF = dF; P.mdf = df; P.mdx0 = dx0;
     P.info = info;
     P.workspace = (double *)workspace;
-    return r16n_backward(P, stream);
+    if (kind == MPC_R16N) return r16n_backward(P, stream);
+    if (!C || !F) return DQP_ERR_BAD_ARG;
+    P.mC = C; P.mF = F;
+    return ric_backward(P, stream);
 }
 
 __attribute__((visibility("default"))) int

@@ -1,0 +1,631 @@
+// dqp_ric.hip -- stage-wise PDIPM for MPC-structured QPs of any horizon: the same Mehrotra
+// predictor-corrector iteration as the dense kernels (reference: qpth/solvers/pdipm/batch.py:46-208,
+// batch_LU.py:29-201 behind qpth/qp_wrapper.py:299-335), with every KKT solve done by a Riccati
+// recursion over the knots instead of a dense factorisation -- O(T (n+m)^3) instead of
+// O(T^3 (n+m)^3), which is what makes BASELINE config 4 (n = 12, m = 4, T = 30: nz = 480) a
+// one-kernel problem (SURVEY.md §8 f1 / row g).
+//
+// Problem (qp_wrapper.py:638-679, never assembled): knots tau_t = [x_t ; u_t], t = 0..T-1,
+//     min  sum_t 1/2 tau_t' C_t tau_t + c_t' tau_t
+//     s.t. F_t tau_t - x_{t+1} = -f_t  (t < T-1),   x_0 = x0,   u_lower <= u_t <= u_upper
+// with the reference's orderings: z = [tau_0 .. tau_{T-1}], y = [dynamics rows t = 0..T-2 ; x_0 rows],
+// lam = [upper rows, t-major ; lower rows, t-major].
+//
+// One KKT solve (batch.py:351-374 solve_kkt, any right-hand side (rx, rs, rz, ry)):
+//     eliminate ds, dz:   Phi_t = C_t + diag(0, d_up + d_lo),   rhs1 = -rx + G'(rs - D rz)
+//     [Phi A' ; A 0] [dx ; dy] = [rhs1 ; -ry]   is an LQR problem, solved by
+//       backward  H_t = Phi_t + F_t' P_{t+1} F_t ;  partial Cholesky of H_t on its control pivots leaves
+//                 P_t (state block), Lxu, Luu in place ;  the same elimination on the vector
+//                 h_t = q_t + F_t'(P_{t+1} e_t + p_{t+1}) leaves p_t and Luu^-1 h_u
+//       forward   du_t = -Luu^-T (Luu^-1 h_u + Lxu' dx_t) ;  dx_{t+1} = F_t dtau_t + e_t ;
+//                 dy_t = P_{t+1} dx_{t+1} + p_{t+1} ;  dy_init = -(P_0 dx_0 + p_0)
+//     (q = -rhs1, e = ry, dx_0 = -ry_init), then ds = -rz - G dx, dz = -rs - D ds.
+// The factorisation is shared by the affine and the corrector solve of an iteration.
+//
+// Layout: one QP per 16-lane DPP row (n + m <= 16: a knot is one distributed vector, a stage matrix
+// one row per lane), four QPs per wavefront, iterates / directions / per-knot factors streamed through
+// a caller workspace (dqp_mpc_qp_workspace_bytes) -- the kernel is HBM-stream bound by C, F and the
+// factors (~40 k doubles per QP and iteration at config 4).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/dqp.h"
+#include "dqp_common.h"
+#include "dqp_r16_prims.h"
+
+namespace dqp {
+namespace ric {
+
+using namespace dqp::r16;
+
+template <int NX_, int NU_> struct Cfg {
+    static constexpr int NX = NX_, NU = NU_, NT = NX_ + NU_;
+    static_assert(NT <= 16, "a knot must fit a 16-lane DPP row");
+};
+
+// per-QP workspace (doubles); everything knot-major
+struct Lay {
+    int X, Y, SU, SL, ZU, ZL;            // iterate
+    int RX, RY, RZU, RZL;                // residuals of the iterate
+    int DX, DY, DSU, DSL, DZU, DZL;      // step (affine, then affine + corrector)
+    int BX, BY, BSU, BSL, BZU, BZL;      // best iterate
+    int FAC, PV, YB;                     // per knot: eliminated H rows (NT x NT), p_t (NX), Luu^-1 h_u (NU)
+    int total;
+};
+__host__ __device__ inline Lay layout(int nx, int nu, int T)
+{
+    const int nt = nx + nu;
+    Lay L;
+    int o = 0;
+    auto take = [&](int n) { const int at = o; o += n; return at; };
+    L.X = take(T * nt); L.Y = take(T * nx); L.SU = take(T * nu); L.SL = take(T * nu); L.ZU = take(T * nu); L.ZL = take(T * nu);
+    L.RX = take(T * nt); L.RY = take(T * nx); L.RZU = take(T * nu); L.RZL = take(T * nu);
+    L.DX = take(T * nt); L.DY = take(T * nx); L.DSU = take(T * nu); L.DSL = take(T * nu); L.DZU = take(T * nu); L.DZL = take(T * nu);
+    L.BX = take(T * nt); L.BY = take(T * nx); L.BSU = take(T * nu); L.BSL = take(T * nu); L.BZU = take(T * nu); L.BZL = take(T * nu);
+    L.FAC = take(T * nt * nt); L.PV = take(T * nx); L.YB = take(T * nu);
+    L.total = (o + 1) & ~1;
+    return L;
+}
+
+enum Mode { INIT = 0, AFFINE = 1, CORRECTOR = 2, ADJOINT = 3 };
+
+template <class C> struct Ctx {
+    const KParams &P;
+    double *w;                      // this QP's workspace
+    Lay L;
+    long long qp;
+    int r, T;
+    bool xl, ul, live;              // lane holds a state row / a control row / a real problem
+    int a;                          // control index of a control lane (0 otherwise)
+    double uu, ulo;                 // bounds of this lane's control
+    __device__ const double *Crow(int t) const { return P.mC + (((long long)t * P.B + qp) * C::NT + (r < C::NT ? r : 0)) * C::NT; }
+    __device__ const double *Frow(int t) const { return P.mF + (((long long)t * P.B + qp) * C::NX + (xl ? r : 0)) * C::NT; }
+    __device__ const double *Fmat(int t) const { return P.mF + ((long long)t * P.B + qp) * C::NX * C::NT; }
+};
+
+// y[r] = sum_c row[c] * v[c]  (row = this lane's matrix row, v distributed)
+template <int N> __device__ __forceinline__ double mv_row(const double (&row)[N], double v)
+{
+    double acc = 0.0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) acc = fma(row[c], rb(v, c), acc);
+    return acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// residuals of the iterate in X, Y, S*, Z* (batch.py:93-108): rx = C tau + c + G'z + A'y,
+// rz = G tau + s - h, ry = A tau - b; returns (||rx||^2, ||rz||^2, ||ry||^2, s'z) partials (lane-local)
+template <class C>
+__device__ __forceinline__ void residuals(const Ctx<C> &K, double &nx2, double &nz2, double &ny2, double &sz)
+{
+    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    const int r = K.r, T = K.T;
+    double *w = K.w;
+    const Lay &L = K.L;
+    nx2 = nz2 = ny2 = sz = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double tau = r < NT ? w[L.X + t * NT + r] : 0.0;
+        double crow[NT];
+        const double *cp = K.Crow(t);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) crow[c] = cp[c];
+        double rx = mv_row<NT>(crow, tau) + (r < NT ? K.P.mc[((long long)t * K.P.B + K.qp) * NT + r] : 0.0);
+        if (K.ul) {
+            const int iu = t * NU + K.a;
+            const double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
+            rx += zu - zl;
+            const double rzu = tau - K.uu + su, rzl = -tau + K.ulo + sl;
+            w[L.RZU + iu] = rzu; w[L.RZL + iu] = rzl;
+            nz2 = fma(rzu, rzu, fma(rzl, rzl, nz2));
+            sz = fma(su, zu, fma(sl, zl, sz));
+        }
+        if (t < T - 1) {
+            const double yt = K.xl ? w[L.Y + t * NX + r] : 0.0;
+            const double *fm = K.Fmat(t);
+            double acc = 0.0;                        // (F' y)[r] = sum_i F[i][r] y[i]
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc = fma(r < NT ? fm[i * NT + r] : 0.0, rb(yt, i), acc);
+            rx += acc;
+            double frow[NT];
+            const double *fp = K.Frow(t);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) frow[c] = fp[c];
+            const double fx = mv_row<NT>(frow, tau);
+            if (K.xl) {
+                const double ry = fx - w[L.X + (t + 1) * NT + r] + K.P.mf[((long long)t * K.P.B + K.qp) * NX + r];
+                w[L.RY + t * NX + r] = ry;
+                ny2 = fma(ry, ry, ny2);
+            }
+        }
+        if (K.xl) {
+            if (t >= 1) rx -= w[L.Y + (t - 1) * NX + r];
+            else {
+                rx += w[L.Y + (T - 1) * NX + r];
+                const double ry = tau - K.P.mx0[K.qp * NX + r];
+                w[L.RY + (T - 1) * NX + r] = ry;
+                ny2 = fma(ry, ry, ny2);
+            }
+        }
+        if (r < NT) { w[L.RX + t * NT + r] = rx; nx2 = fma(rx, rx, nx2); }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward Riccati sweep on the matrices; d = z/s from the iterate (unit: d = 1, clampd: the
+// reference's backward clamps, qp.py:131-134).  Returns false if a control pivot is not positive.
+template <class C>
+__device__ __forceinline__ bool factor(const Ctx<C> &K, bool unit, bool clampd)
+{
+    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    const int r = K.r, T = K.T;
+    double *w = K.w;
+    const Lay &L = K.L;
+    double Pn[NX];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) Pn[c] = 0.0;
+    bool ok = true;
+    for (int t = T - 1; t >= 0; --t) {
+        double H[NT];
+        const double *cp = K.Crow(t);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) H[c] = r < NT ? cp[c] : (r == c ? 1.0 : 0.0);
+        if (K.ul) {
+            const int iu = t * NU + K.a;
+            double dd = 2.0;
+            if (!unit) {
+                double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
+                if (clampd) { su = fmax(su, 1e-8); sl = fmax(sl, 1e-8); zu = fmax(zu, 1e-8); zl = fmax(zl, 1e-8); }
+                dd = zu / su + zl / sl;
+            }
+#pragma unroll
+            for (int c = 0; c < NT; ++c) H[c] += (r == c) ? dd : 0.0;
+        }
+        if (t < T - 1) {
+            double frow[NT], fcol[NX], PF[NT];
+            const double *fp = K.Frow(t), *fm = K.Fmat(t);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) frow[c] = K.xl ? fp[c] : 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) fcol[i] = r < NT ? fm[i * NT + r] : 0.0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {                  // PF = P_{t+1} F_t, row-distributed over the state lanes
+                double acc = 0.0;
+#pragma unroll
+                for (int c = 0; c < NX; ++c) acc = fma(Pn[c], rb(frow[j], c), acc);
+                PF[j] = acc;
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {                  // H += F_t' (P F)
+                double acc = H[b];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) acc = fma(fcol[i], rb(PF[b], i), acc);
+                H[b] = acc;
+            }
+        }
+        // partial Cholesky on the control pivots j = NX .. NT-1
+        double rdj_keep = 0.0;
+#pragma unroll
+        for (int j = NX; j < NT; ++j) {
+            const double pj = rb(H[j], j);
+            if (!(pj > 0.0)) ok = false;
+            const double rdj = frsqrt(pj > 0.0 ? pj : 1.0);
+            const double lij = H[j] * rdj;                  // column j of L on every lane (lane j: sqrt(pj))
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                if (c >= NX && c <= j) continue;            // L columns already final
+                H[c] = fma(-lij, rb(lij, c), H[c]);
+            }
+            H[j] = lij;
+            if (r == j) rdj_keep = rdj;
+        }
+        if (K.ul) H[0] = rdj_keep;                          // control lanes: 1 / L_jj parked in an unused slot
+        if (r < NT) {
+            double *o = w + L.FAC + ((long long)t * NT + r) * NT;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) o[c] = H[c];
+        }
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Pn[c] = K.xl ? H[c] : 0.0;
+    }
+    return ok;
+}
+
+// right-hand side of one stage for the four uses of the solver: q_t[r] (= -rhs1) and e_t[r]
+template <class C, int MODE>
+__device__ __forceinline__ void stage_rhs(const Ctx<C> &K, int t, double musig, double &q, double &e)
+{
+    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    const int r = K.r, T = K.T;
+    const double *w = K.w;
+    const Lay &L = K.L;
+    q = 0.0; e = 0.0;
+    if (MODE == INIT) {            // batch.py:60-74: rx = p, rs = 0, rz = -h, ry = -b with d = 1
+        if (r < NT) q = K.P.mc[((long long)t * K.P.B + K.qp) * NT + r];
+        if (K.ul) q -= K.uu + K.ulo;
+        if (K.xl && t < T - 1) e = K.P.mf[((long long)t * K.P.B + K.qp) * NX + r];
+    } else if (MODE == AFFINE) {   // rx, rs = z, rz, ry of the iterate
+        if (r < NT) q = w[L.RX + t * NT + r];
+        if (K.ul) {
+            const int iu = t * NU + K.a;
+            const double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
+            q -= (zu - zu / su * w[L.RZU + iu]) - (zl - zl / sl * w[L.RZL + iu]);
+        }
+        if (K.xl && t < T - 1) e = w[L.RY + t * NX + r];
+    } else if (MODE == CORRECTOR) {   // rx = 0, rs = (-mu sig + ds_aff dz_aff) / s, rz = ry = 0
+        if (K.ul) {
+            const int iu = t * NU + K.a;
+            const double rsu = (-musig + w[L.DSU + iu] * w[L.DZU + iu]) / w[L.SU + iu];
+            const double rsl = (-musig + w[L.DSL + iu] * w[L.DZL + iu]) / w[L.SL + iu];
+            q = -(rsu - rsl);
+        }
+    } else {                       // ADJOINT: rx = dl/dzhat (qp.py:136-141)
+        if (r < NT) q = K.P.gin[(K.qp * T + t) * NT + r];            // dl/dtau is (B, T, nt) like tau
+    }
+}
+
+// backward vector sweep: p_t and Luu^-1 h_u per stage
+template <class C, int MODE>
+__device__ __forceinline__ void sweep_back(const Ctx<C> &K, double musig)
+{
+    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    const int r = K.r, T = K.T;
+    double *w = K.w;
+    const Lay &L = K.L;
+    double pn = 0.0;
+    for (int t = T - 1; t >= 0; --t) {
+        double q, e;
+        stage_rhs<C, MODE>(K, t, musig, q, e);
+        double h = q;
+        if (t < T - 1) {
+            const double *pr = w + L.FAC + ((long long)(t + 1) * NT + (K.xl ? r : 0)) * NT;
+            double v = pn;
+            if (MODE == INIT || MODE == AFFINE) {
+#pragma unroll
+                for (int c = 0; c < NX; ++c) v = fma(K.xl ? pr[c] : 0.0, rb(e, c), v);
+            }
+            const double *fm = K.Fmat(t);
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc = fma(r < NT ? fm[i * NT + r] : 0.0, rb(v, i), acc);
+            h += acc;
+        }
+        const double *lr = w + L.FAC + ((long long)t * NT + (r < NT ? r : 0)) * NT;
+        const double rd = K.ul ? lr[0] : 0.0;
+#pragma unroll
+        for (int j = NX; j < NT; ++j) {
+            const double hj = rb(h, j) * rb(rd, j);
+            const double lij = (r < NT && (r < NX || r > j)) ? lr[j] : 0.0;
+            h = (r == j) ? hj : fma(-lij, hj, h);
+        }
+        if (K.xl) w[L.PV + t * NX + r] = h;
+        if (K.ul) w[L.YB + t * NU + K.a] = h;
+        pn = K.xl ? h : 0.0;
+    }
+}
+
+// forward sweep: dtau, dy, ds, dz of the solve; returns the lane-local minimum step ratio of
+// (s, z) against the direction that ends up in D* (affine: this solve; corrector: affine + this)
+template <class C, int MODE>
+__device__ __forceinline__ double sweep_fwd(const Ctx<C> &K, double musig)
+{
+    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    const int r = K.r, T = K.T;
+    double *w = K.w;
+    const Lay &L = K.L;
+    double ratio = INFINITY;
+    // dx_0 = -ry_init
+    double dx = 0.0;
+    if (K.xl) {
+        if (MODE == INIT) dx = K.P.mx0[K.qp * NX + r];
+        else if (MODE == AFFINE) dx = -w[L.RY + (T - 1) * NX + r];
+    }
+    {   // dy_init = -(P_0 dx_0 + p_0)
+        const double *pr = w + L.FAC + (long long)(K.xl ? r : 0) * NT;
+        double v = K.xl ? w[L.PV + r] : 0.0;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) v = fma(K.xl ? pr[c] : 0.0, rb(dx, c), v);
+        if (K.xl) {
+            double *o = w + L.DY + (T - 1) * NX + r;
+            *o = (MODE == CORRECTOR) ? *o - v : -v;
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+        const double *lr = w + L.FAC + ((long long)t * NT + (r < NT ? r : 0)) * NT;
+        double lrow[NU];
+#pragma unroll
+        for (int b = 0; b < NU; ++b) lrow[b] = r < NT ? lr[NX + b] : 0.0;
+        const double rd = K.ul ? lr[0] : 0.0;
+        double zz = K.ul ? w[L.YB + t * NU + K.a] : 0.0;
+#pragma unroll
+        for (int b = 0; b < NU; ++b) {
+            const double wb = row_sum(K.xl ? lrow[b] * dx : 0.0);        // (Lxu' dx)[b]
+            if (r == NX + b) zz += wb;
+        }
+        double yv = 0.0;                                                   // Luu' yv = zz
+#pragma unroll
+        for (int j = NT - 1; j >= NX; --j) {
+            const double s = row_sum((r > j && r < NT) ? lrow[j - NX] * yv : 0.0);
+            if (r == j) yv = (zz - s) * rd;
+        }
+        const double dtau = K.xl ? dx : (K.ul ? -yv : 0.0);
+        if (r < NT) {
+            double *o = w + L.DX + t * NT + r;
+            *o = (MODE == CORRECTOR) ? *o + dtau : dtau;
+        }
+        if (K.ul && MODE != ADJOINT) {
+            const int iu = t * NU + K.a;
+            if (MODE == INIT) {            // s = ds = -rz - G dx,  z = dz = -ds   (d = 1, rs = 0)
+                const double su = K.uu - dtau, sl = dtau - K.ulo;
+                w[L.SU + iu] = su; w[L.SL + iu] = sl; w[L.ZU + iu] = -su; w[L.ZL + iu] = -sl;
+            } else {
+                const double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
+                double dsu, dsl, dzu, dzl;
+                if (MODE == AFFINE) {
+                    dsu = -w[L.RZU + iu] - dtau; dsl = -w[L.RZL + iu] + dtau;
+                    dzu = -zu - zu / su * dsu;   dzl = -zl - zl / sl * dsl;
+                } else {
+                    const double asu = w[L.DSU + iu], asl = w[L.DSL + iu], azu = w[L.DZU + iu], azl = w[L.DZL + iu];
+                    const double rsu = (-musig + asu * azu) / su, rsl = (-musig + asl * azl) / sl;
+                    const double csu = -dtau, csl = dtau;
+                    dsu = asu + csu; dsl = asl + csl;
+                    dzu = azu + (-rsu - zu / su * csu); dzl = azl + (-rsl - zl / sl * csl);
+                }
+                w[L.DSU + iu] = dsu; w[L.DSL + iu] = dsl; w[L.DZU + iu] = dzu; w[L.DZL + iu] = dzl;
+                // get_step (batch.py:206-214, with batch_LU's dv == 0 guard): a = -v/dv where dv < 0
+                ratio = fmin(ratio, dsu < 0.0 ? -su / dsu : INFINITY);
+                ratio = fmin(ratio, dsl < 0.0 ? -sl / dsl : INFINITY);
+                ratio = fmin(ratio, dzu < 0.0 ? -zu / dzu : INFINITY);
+                ratio = fmin(ratio, dzl < 0.0 ? -zl / dzl : INFINITY);
+            }
+        }
+        if (t < T - 1) {
+            double frow[NT];
+            const double *fp = K.Frow(t);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) frow[c] = K.xl ? fp[c] : 0.0;
+            double q, e;
+            stage_rhs<C, MODE>(K, t, musig, q, e);
+            const double dxn = mv_row<NT>(frow, dtau) + e;
+            const double *pr = w + L.FAC + ((long long)(t + 1) * NT + (K.xl ? r : 0)) * NT;
+            double v = K.xl ? w[L.PV + (t + 1) * NX + r] : 0.0;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) v = fma(K.xl ? pr[c] : 0.0, rb(dxn, c), v);
+            if (K.xl) {
+                double *o = w + L.DY + t * NX + r;
+                *o = (MODE == CORRECTOR) ? *o + v : v;
+            }
+            dx = K.xl ? dxn : 0.0;
+        }
+    }
+    return ratio;
+}
+
+// element-wise helpers over the constraint arrays (length 2 T NU, lanes strided)
+template <class C>
+__device__ __forceinline__ void copy_best(const Ctx<C> &K)
+{
+    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    double *w = K.w;
+    const Lay &L = K.L;
+    const int T = K.T, r = K.r;
+    for (int i = r; i < T * NT; i += 16) w[L.BX + i] = w[L.X + i];
+    for (int i = r; i < T * NX; i += 16) w[L.BY + i] = w[L.Y + i];
+    for (int i = r; i < T * NU; i += 16) {
+        w[L.BSU + i] = w[L.SU + i]; w[L.BSL + i] = w[L.SL + i];
+        w[L.BZU + i] = w[L.ZU + i]; w[L.BZL + i] = w[L.ZL + i];
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(64) void forward_kernel(KParams P, int T)
+{
+    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    const int lane = threadIdx.x, r = lane & 15;
+    long long qp = (long long)blockIdx.x * 4 + (lane >> 4);
+    bool live = qp < P.B;
+    if (!live) qp = P.B - 1;
+    int maxIter = P.maxIter;
+    const bool batch = (P.flags & DQP_FLAG_BATCH_TERMINATION) != 0;
+    if (P.cap) {        // pass 2 of the batch rule: only the listed QPs, up to the reference's stop
+        maxIter = min(maxIter, P.cap[0]);
+        live = live && P.cap[TERM_HDR + qp] != 0;
+        if (__builtin_amdgcn_ballot_w64(live) == 0) return;
+    }
+    term_zero_acc(P);
+    const Lay L = layout(NX, NU, T);
+    // a duplicated (padding) row works on its own copy of the last problem's scratch: rows must not race
+    const long long slot = (long long)blockIdx.x * 4 + (lane >> 4);
+    Ctx<C> K = {P, P.workspace + slot * (long long)L.total, L, qp, r, T, r < NX, r >= NX && r < NT, live,
+                (r >= NX && r < NT) ? r - NX : 0, 0.0, 0.0};
+    K.uu = P.muu[K.a]; K.ulo = P.mul[K.a];
+    double *w = K.w;
+    const int nineq = 2 * T * NU;
+    int status = DQP_STATUS_OK;
+
+    // ---- initial point (batch.py:60-86)
+    if (!factor<C>(K, true, false)) status = DQP_STATUS_Q_NOT_PD;
+    sweep_back<C, INIT>(K, 0.0);
+    sweep_fwd<C, INIT>(K, 0.0);
+    {
+        for (int i = r; i < T * NT; i += 16) w[L.X + i] = w[L.DX + i];
+        for (int i = r; i < T * NX; i += 16) w[L.Y + i] = w[L.DY + i];
+        double ms = INFINITY, mz = INFINITY;
+        for (int i = r; i < T * NU; i += 16) {
+            ms = fmin(ms, fmin(w[L.SU + i], w[L.SL + i]));
+            mz = fmin(mz, fmin(w[L.ZU + i], w[L.ZL + i]));
+        }
+        ms = row_min(ms); mz = row_min(mz);
+        for (int i = r; i < T * NU; i += 16) {
+            if (ms < 0.0) { w[L.SU + i] -= ms - 1.0; w[L.SL + i] -= ms - 1.0; }
+            if (mz < 0.0) { w[L.ZU + i] -= mz - 1.0; w[L.ZL + i] -= mz - 1.0; }
+        }
+    }
+
+    double best = INFINITY;
+    bool have_best = false, done = false;
+    int nNot = 0, iters = 0;
+    for (int it = 0; it < maxIter; ++it) {
+        double nx2, nz2, ny2, sz;
+        residuals<C>(K, nx2, nz2, ny2, sz);
+        nx2 = row_sum(nx2); nz2 = row_sum(nz2); ny2 = row_sum(ny2); sz = row_sum(sz);
+        const double mu = fabs(sz / nineq);
+        const double resid = sqrt(nz2) + sqrt(ny2) + sqrt(nx2) + nineq * mu;
+        if (!done) {
+            iters = it + 1;
+            if (!have_best || resid < best) { nNot = 0; have_best = true; best = resid; copy_best<C>(K); }
+            else nNot += 1;
+            if (batch) {
+                if (P.hist && r == 0 && live) hist_put(P, qp, it, resid, mu);
+                done = !(fabs(resid) < INFINITY);
+            } else if ((nNot >= P.notImprovedLim && best < P.stallTol) || best < P.eps || mu > 1e32 ||
+                       !(fabs(resid) < INFINITY))
+                done = true;
+        }
+        if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
+
+        if (!factor<C>(K, false, false) && status == DQP_STATUS_OK) status = DQP_STATUS_Q_NOT_PD;
+        // affine direction and its step (batch.py:147-163)
+        sweep_back<C, AFFINE>(K, 0.0);
+        double ra = row_min(sweep_fwd<C, AFFINE>(K, 0.0));
+        const double alpha_a = fmin(ra, 1.0);
+        double t3 = 0.0;
+        for (int i = r; i < T * NU; i += 16) {
+            t3 = fma(w[L.SU + i] + alpha_a * w[L.DSU + i], w[L.ZU + i] + alpha_a * w[L.DZU + i], t3);
+            t3 = fma(w[L.SL + i] + alpha_a * w[L.DSL + i], w[L.ZL + i] + alpha_a * w[L.DZL + i], t3);
+        }
+        t3 = row_sum(t3);
+        double sig = t3 / sz;
+        sig = sig * sig * sig;
+        // corrector (batch.py:165-181), step (batch.py:183-204)
+        sweep_back<C, CORRECTOR>(K, mu * sig);
+        const double rc = row_min(sweep_fwd<C, CORRECTOR>(K, mu * sig));
+        const double alpha = fmin(0.999 * rc, 1.0);
+        if (!done) {
+            for (int i = r; i < T * NT; i += 16) w[L.X + i] += alpha * w[L.DX + i];
+            for (int i = r; i < T * NX; i += 16) w[L.Y + i] += alpha * w[L.DY + i];
+            for (int i = r; i < T * NU; i += 16) {
+                w[L.SU + i] += alpha * w[L.DSU + i]; w[L.SL + i] += alpha * w[L.DSL + i];
+                w[L.ZU + i] += alpha * w[L.DZU + i]; w[L.ZL + i] += alpha * w[L.DZL + i];
+            }
+        }
+    }
+    if (P.hist && r == 0 && live) hist_fill(P, qp, iters);
+    if (!have_best) {       // max_iter == 0 cannot happen (checked on the host); kept for symmetry
+        copy_best<C>(K);
+    }
+    // ---- outputs in the reference's orderings
+    if (live) {
+        const int nz = T * NT, neq = T * NX, hm = T * NU;
+        for (int i = r; i < nz; i += 16) P.zhat[qp * nz + i] = w[L.BX + i];
+        for (int i = r; i < neq; i += 16) P.nu[qp * neq + i] = w[L.BY + i];
+        for (int i = r; i < hm; i += 16) {
+            P.lam[qp * 2 * hm + i] = w[L.BZU + i];       P.lam[qp * 2 * hm + hm + i] = w[L.BZL + i];
+            P.slack[qp * 2 * hm + i] = w[L.BSU + i];     P.slack[qp * 2 * hm + hm + i] = w[L.BSL + i];
+        }
+        if (r == 0) {
+            if (P.info) { P.info[2 * qp] = status; P.info[2 * qp + 1] = iters; }
+            if (P.best_resid) P.best_resid[qp] = best;
+        }
+    }
+}
+
+// Backward (qp.py:128-183; DenseQPFunction's un-clamped d with DQP_FLAG_DENSE_BACKWARD, qp.py:246-250):
+// one factorisation with d = lam/slack of the returned iterate, one solve with rhs (dl/dzhat, 0, 0, 0),
+// gradients scattered straight into the MPC parameters.
+template <class C>
+__global__ __launch_bounds__(64) void backward_kernel(KParams P, int T)
+{
+    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    const int lane = threadIdx.x, r = lane & 15;
+    long long qp = (long long)blockIdx.x * 4 + (lane >> 4);
+    const bool live = qp < P.B;
+    if (!live) qp = P.B - 1;
+    const Lay L = layout(NX, NU, T);
+    const long long slot = (long long)blockIdx.x * 4 + (lane >> 4);
+    Ctx<C> K = {P, P.workspace + slot * (long long)L.total, L, qp, r, T, r < NX, r >= NX && r < NT, live,
+                (r >= NX && r < NT) ? r - NX : 0, 0.0, 0.0};
+    double *w = K.w;
+    const int nz = T * NT, neq = T * NX, hm = T * NU;
+    for (int i = r; i < hm; i += 16) {
+        w[L.ZU + i] = P.lamin[qp * 2 * hm + i];     w[L.ZL + i] = P.lamin[qp * 2 * hm + hm + i];
+        w[L.SU + i] = P.slackin[qp * 2 * hm + i];   w[L.SL + i] = P.slackin[qp * 2 * hm + hm + i];
+    }
+    int status = DQP_STATUS_OK;
+    if (!factor<C>(K, false, !(P.flags & DQP_FLAG_DENSE_BACKWARD))) status = DQP_STATUS_Q_NOT_PD;
+    sweep_back<C, ADJOINT>(K, 0.0);
+    sweep_fwd<C, ADJOINT>(K, 0.0);
+    if (!live) return;
+    const long long Bq = P.B;
+    // dc = dx ;  dC_t = 1/2 (dx_t tau_t' + tau_t dx_t') ;  dF_t = dnu_t tau_t' + nu_t dx_t' ;  df_t = dnu_t ;
+    // dx0 = -dnu_init    (qp.py:143-178 restricted to the blocks the MPC parameters occupy)
+    for (int t = 0; t < T; ++t) {
+        const double dxr = r < NT ? w[L.DX + t * NT + r] : 0.0;
+        const double zr = r < NT ? P.zin[qp * nz + t * NT + r] : 0.0;
+        if (P.mdc && r < NT) P.mdc[((long long)t * Bq + qp) * NT + r] = dxr;
+        if (P.mdC) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const double v = 0.5 * (rb(dxr, i) * zr + rb(zr, i) * dxr);
+                if (r < NT) P.mdC[(((long long)t * Bq + qp) * NT + i) * NT + r] = v;
+            }
+        }
+        if (t < T - 1) {
+            const double dn = K.xl ? w[L.DY + t * NX + r] : 0.0;
+            const double nn = K.xl ? P.nuin[qp * neq + t * NX + r] : 0.0;
+            if (P.mdF) {
+#pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const double v = rb(dn, i) * zr + rb(nn, i) * dxr;
+                    if (r < NT) P.mdF[(((long long)t * Bq + qp) * NX + i) * NT + r] = v;
+                }
+            }
+            if (P.mdf && K.xl) P.mdf[((long long)t * Bq + qp) * NX + r] = dn;
+        }
+    }
+    if (P.mdx0 && K.xl) P.mdx0[qp * NX + r] = -w[L.DY + (T - 1) * NX + r];
+    if (r == 0 && P.info) { P.info[2 * qp] = status; P.info[2 * qp + 1] = 0; }
+}
+
+template <class C, class Kern> int launch(Kern kernel, const KParams &P, int T, void *stream)
+{
+    const int blocks = (P.B + 3) / 4;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, P, T);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+}  // namespace ric
+
+// size table: (n_state, n_ctrl) pairs with a stage-wise kernel
+#define DQP_RIC_SIZES X(12, 4) X(3, 3) X(3, 1) X(4, 1) X(6, 1) X(2, 1) X(4, 2)
+
+bool ric_supported(int n, int m)
+{
+#define X(a, b) if (n == a && m == b) return true;
+    DQP_RIC_SIZES
+#undef X
+    return false;
+}
+
+long long ric_workspace_doubles(int n, int m, int T)
+{
+    return ric_supported(n, m) ? ric::layout(n, m, T).total : 0;
+}
+
+int ric_forward(const KParams &P, void *stream)
+{
+#define X(a, b) if (P.mn == a && P.mm == b) return ric::launch<ric::Cfg<a, b>>(ric::forward_kernel<ric::Cfg<a, b>>, P, P.mT, stream);
+    DQP_RIC_SIZES
+#undef X
+    return 1;
+}
+
+int ric_backward(const KParams &P, void *stream)
+{
+#define X(a, b) if (P.mn == a && P.mm == b) return ric::launch<ric::Cfg<a, b>>(ric::backward_kernel<ric::Cfg<a, b>>, P, P.mT, stream);
+    DQP_RIC_SIZES
+#undef X
+    return 1;
+}
+
+}  // namespace dqp

@@ -176,14 +176,14 @@ class _MPCQP(Function):
         ctx.dims, ctx.ws = dims, ws
         ctx.shapes = (C.shape, c.shape, F.shape, f.shape, x0.shape)
         ctx.dtype = x0.dtype
-        ctx.save_for_backward(tau, lam, nu, slack)
+        ctx.save_for_backward(tau, lam, nu, slack, keep[0], keep[2])     # C, F: the stage-wise backward refactors
         ctx.info, ctx.resid = info, resid
         return tau.to(x0.dtype)
 
     @staticmethod
     def backward(ctx, dtau):
         lib = _lib.load()
-        tau, lam, nu, slack = ctx.saved_tensors
+        tau, lam, nu, slack, C64, F64 = ctx.saved_tensors
         dev = tau.device
         kw = dict(dtype=torch.float64, device=dev)
         need = ctx.needs_input_grad
@@ -191,7 +191,7 @@ class _MPCQP(Function):
         g = dtau.detach().double().contiguous()
         opts = _lib.dqp_opts(0.0, 0.0, 0, 0, _lib.DQP_FLAG_DENSE_BACKWARD, 0)
         with torch.cuda.device(dev):
-            rc = lib.dqp_mpc_qp_backward(ctypes.byref(ctx.dims), ctypes.byref(opts), _ptr(tau), _ptr(lam),
+            rc = lib.dqp_mpc_qp_backward(ctypes.byref(ctx.dims), ctypes.byref(opts), _ptr(C64), _ptr(F64), _ptr(tau), _ptr(lam),
                                          _ptr(nu), _ptr(slack), _ptr(g), *[_ptr(o) for o in outs],
                                          ctypes.c_void_p(0), _ptr(ctx.ws), _stream(dev))
         _lib.check(rc, "dqp_mpc_qp_backward")

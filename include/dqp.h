@@ -212,8 +212,14 @@ int dqp_mpc_assemble_backward(const dqp_mpc_dims *dims, const double *dQ, const 
  * registers from (C,c,F,f,x0,bounds) and solves; backward scatters straight into
  * (dC,dc,dF,df,dx0) (the adjoint of the assembly applied on chip).  HBM traffic per QP at
  * n=3 m=3 T=5: 0.7 k doubles in instead of 2.3 k, 0.3 k gradient doubles out instead of 2.3 k.
- * Needs control bounds, a size with a null-space kernel (dqp_mpc_qp_supported) and the workspace
- * (dqp_mpc_qp_workspace_bytes), which carries the factorisation context from forward to backward.
+ * Needs control bounds, a supported shape (dqp_mpc_qp_supported) and the workspace
+ * (dqp_mpc_qp_workspace_bytes).  Two kernel families serve it:
+ *   - QP sizes with a null-space kernel (small horizons, nz <= 48): the whole QP lives in registers, the
+ *     workspace carries the factorisation context from forward to backward (C, F unused by backward);
+ *   - any other horizon with n_state + n_ctrl <= 16 and a compiled (n_state, n_ctrl) pair -- e.g.
+ *     BASELINE config 4: n 12, m 4, T 30, nz 480 --: stage-wise PDIPM, every KKT solve a Riccati
+ *     recursion over the knots (O(T (n+m)^3)); iterates and per-knot factors stream through the
+ *     workspace; backward refactors at the returned iterate and needs C and F again.
  * tau (B, T, n_state+n_ctrl) = the QP solution per knot [x_t, u_t]; lam/nu/slack/info/best_resid and
  * the termination modes as in dqp_qp_forward; backward = DenseQPFunction's (un-clamped d).
  */
@@ -224,8 +230,8 @@ int dqp_mpc_qp_forward(const dqp_mpc_dims *dims, const dqp_opts *opts, const dou
                        const double *u_upper, double *tau, double *lam, double *nu, double *slack,
                        int32_t *info, double *best_resid, void *workspace, void *termination,
                        void *stream);
-int dqp_mpc_qp_backward(const dqp_mpc_dims *dims, const dqp_opts *opts, const double *tau,
-                        const double *lam, const double *nu, const double *slack,
+int dqp_mpc_qp_backward(const dqp_mpc_dims *dims, const dqp_opts *opts, const double *C, const double *F,
+                        const double *tau, const double *lam, const double *nu, const double *slack,
                         const double *dl_dtau, double *dC, double *dc, double *dF, double *df,
                         double *dx0, int32_t *info, void *workspace, void *stream);
 

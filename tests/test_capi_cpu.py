@@ -56,7 +56,7 @@ def test_workspace_bytes_is_a_host_function(lib):
     from diff_qp_mpc_amd import _lib, _build
     for nz, nineq, neq in _build.R16N_SIZES:
         d = _lib.dqp_dims(7, nz, nineq, neq, 0, 0, 0, 0, 0, 0)
-        per_qp = (neq * (nz - neq) + neq * (neq - 1) // 2) + nz * (nz + 1) // 2 + nineq * nz + neq * neq + 2 * neq + nz
+        per_qp = (neq * (nz - neq) + neq * (neq - 1) // 2) + nz * (nz + 1) // 2 + nineq * nz + neq * neq + 5 * neq + nz + 1
         assert lib.dqp_workspace_bytes(ctypes.byref(d)) == 7 * per_qp * 8
     for nz, nineq, neq in [(12, 8, 0), (7, 5, 2), (64, 64, 32)]:
         d = _lib.dqp_dims(7, nz, nineq, neq, 0, 0, 0, 0, 0, 0)

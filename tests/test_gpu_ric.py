@@ -1,0 +1,172 @@
+"""Stage-wise (Riccati) PDIPM for MPC-structured QPs (csrc/dqp_ric.hip; SURVEY.md §8 f1 / row g,
+BASELINE config 4 shape n 12, m 4, T 30) through the C ABI (dqp_mpc_qp_forward / _backward).
+
+Checkers: (1) the assemble -> DenseQPFunction pipeline of this package on the dense GPU kernels
+(themselves pinned to the reference goldens) where the dense QP still fits them (nz <= 64);
+(2) the CPU oracle's restatement of the reference's DenseQPFunction (batch_LU.py, what
+qp_wrapper.MPC calls) on the QP assembled in numpy, at sizes no dense GPU kernel covers;
+(3) the reference's own qp_wrapper.MPC outputs at n 12, m 4, T 6 (tests/golden/make_golden_ric.py);
+(4) size-independent KKT properties at the full config-4 size.
+Tolerances as in test_gpu_parity.py: zhat rtol 1e-6 / atol 1e-8, duals rtol 1e-5 / atol 1e-7,
+gradients rtol 1e-4 / atol 1e-6.
+"""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+ZT = dict(rtol=1e-6, atol=1e-8)
+DT = dict(rtol=1e-5, atol=1e-7)
+GT = dict(rtol=1e-4, atol=1e-6)
+
+
+def dev(a, grad=False):
+    t = torch.tensor(np.asarray(a), dtype=torch.float64, device="cuda")
+    return t.requires_grad_() if grad else t
+
+
+def problem(n, m, T, B, seed, active=0.4, spread=0.15):
+    """MPC data in the reference's time-major layout (qp_wrapper.py:124-160): SPD stage costs, mildly
+    unstable linear dynamics, bounds tight enough that a good share of the controls sit on them."""
+    rng = np.random.default_rng(seed)
+    nt = n + m
+    L = rng.standard_normal((T, B, nt, nt)) * 0.3
+    C = L @ L.transpose(0, 1, 3, 2) + np.eye(nt)
+    c = rng.standard_normal((T, B, nt))
+    F = np.concatenate([np.eye(n) + spread * rng.standard_normal((T - 1, B, n, n)),
+                        0.5 * rng.standard_normal((T - 1, B, n, m))], axis=-1)
+    f = 0.1 * rng.standard_normal((T - 1, B, n))
+    x0 = rng.standard_normal((B, n))
+    return C, c, F, f, x0, -active * np.ones(m), active * np.ones(m)
+
+
+def assemble(C, c, F, f, x0, lo, hi):
+    """The dense QP of qp_wrapper.py:638-679 in numpy (reference orderings)."""
+    T, B, nt, _ = C.shape
+    n = x0.shape[1]
+    m = nt - n
+    nz, neq, nineq = T * nt, T * n, 2 * T * m
+    Q = np.zeros((B, nz, nz)); p = np.zeros((B, nz)); A = np.zeros((B, neq, nz)); b = np.zeros((B, neq))
+    G = np.zeros((B, nineq, nz)); h = np.zeros((B, nineq))
+    for t in range(T):
+        Q[:, t * nt:(t + 1) * nt, t * nt:(t + 1) * nt] = C[t]
+        p[:, t * nt:(t + 1) * nt] = c[t]
+        for a in range(m):
+            G[:, t * m + a, t * nt + n + a] = 1.0; h[:, t * m + a] = hi[a]
+            G[:, T * m + t * m + a, t * nt + n + a] = -1.0; h[:, T * m + t * m + a] = -lo[a]
+    for t in range(T - 1):
+        A[:, t * n:(t + 1) * n, t * nt:(t + 1) * nt] = F[t]
+        A[:, t * n:(t + 1) * n, (t + 1) * nt:(t + 1) * nt + n] = -np.eye(n)
+        b[:, t * n:(t + 1) * n] = -f[t]
+    A[:, (T - 1) * n:, :n] = np.eye(n); b[:, (T - 1) * n:] = x0
+    return Q, p, G, h, A, b
+
+
+def run_fused(n, m, T, data, w=None):
+    from diff_qp_mpc_amd import qp_wrapper
+    C, c, F, f, x0, lo, hi = data
+    B = x0.shape[0]
+    assert qp_wrapper._MPCQP.supported(B, n, m, T)
+    ins = [dev(a, grad=True) for a in (C, c, F, f, x0)]
+    tau = qp_wrapper._MPCQP.apply(*ins, dev(lo), dev(hi), n, m, T)
+    if w is None:
+        w = torch.linspace(0.5, 1.5, tau.numel(), dtype=torch.float64, device="cuda").reshape(tau.shape)
+    (tau * w).sum().backward()
+    return tau.detach().cpu().numpy(), [t.grad.cpu().numpy() for t in ins], w.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,m,T,B", [(3, 3, 4, 37), (4, 2, 5, 9), (12, 4, 4, 6), (2, 1, 7, 5)])
+def test_stagewise_equals_assemble_plus_dense_gpu(n, m, T, B):
+    """Same problems through the stage-wise kernels and through dqp_mpc_assemble + DenseQPFunction on
+    the dense GPU kernels (nz <= 64), per-problem termination on both sides so that every QP is
+    compared at its own converged iterate."""
+    from diff_qp_mpc_amd import qp as qpmod, qp_wrapper
+    data = problem(n, m, T, B, seed=n * 100 + T)
+    old = qpmod.TERMINATION
+    qpmod.TERMINATION = "per_problem"
+    try:
+        tau, grads, w = run_fused(n, m, T, data)
+        C, c, F, f, x0, lo, hi = data
+        ins = [dev(a, grad=True) for a in (C, c, F, f, x0)]
+        Q, p, G, h, A, b = qp_wrapper._AssembleDenseQP.apply(*ins, dev(lo), dev(hi), n, m, T)
+        z = qpmod.DenseQPFunction(verbose=-1)(Q, p, G, h, A, b)
+        (z.reshape(B, T, n + m) * dev(w)).sum().backward()
+    finally:
+        qpmod.TERMINATION = old
+    np.testing.assert_allclose(tau.reshape(B, -1), z.detach().cpu().numpy(), **ZT)
+    for a, t, k in zip(grads, ins, ("dC", "dc", "dF", "df", "dx0")):
+        np.testing.assert_allclose(a, t.grad.cpu().numpy(), err_msg=k, **GT)
+
+
+@pytest.mark.parametrize("n,m,T,B", [(12, 4, 6, 5), (3, 1, 14, 8), (12, 4, 12, 3)])
+def test_stagewise_vs_cpu_oracle(n, m, T, B):
+    """Against the CPU oracle's DenseQPFunction restatement (batch_LU.py:29-244, qp.py:239-270) on the
+    numpy-assembled QP: batch-coupled termination on both sides (the default)."""
+    data = problem(n, m, T, B, seed=7 * n + T)
+    tau, grads, w = run_fused(n, m, T, data)
+    Q, p, G, h, A, b = assemble(*data)
+    o = oracle.dense_forward(Q, p, G, h, A, b)
+    np.testing.assert_allclose(tau.reshape(B, -1), o["zhat"], **ZT)
+    og = oracle.dense_backward(o["K"], o["zhat"], o["lam"], o["nu"], w.reshape(B, -1))
+    nt = n + m
+    dC = np.stack([og["dQ"][:, t * nt:(t + 1) * nt, t * nt:(t + 1) * nt] for t in range(T)])
+    dc = np.stack([og["dp"][:, t * nt:(t + 1) * nt] for t in range(T)])
+    dF = np.stack([og["dA"][:, t * n:(t + 1) * n, t * nt:(t + 1) * nt] for t in range(T - 1)])
+    df = np.stack([-og["db"][:, t * n:(t + 1) * n] for t in range(T - 1)])
+    dx0 = og["db"][:, (T - 1) * n:]
+    for a, want, k in zip(grads, (dC, dc, dF, df, dx0), ("dC", "dc", "dF", "df", "dx0")):
+        np.testing.assert_allclose(a, want, err_msg=k, **GT)
+
+
+def test_config4_size_kkt_properties():
+    """n 12, m 4, T 30 (nz 480, nineq 240, neq 360), B = 256: stationarity, primal feasibility,
+    complementarity and sign conditions of the returned (tau, lam, nu, slack) on the original data."""
+    from diff_qp_mpc_amd import _lib
+    n, m, T, B = 12, 4, 30, 256
+    nt = n + m
+    C, c, F, f, x0, lo, hi = problem(n, m, T, B, seed=3, spread=0.05)      # 30 steps: keep the rollout bounded
+    lib = _lib.load()
+    dims = _lib.dqp_mpc_dims(B, n, m, T, 1, 0)
+    assert lib.dqp_mpc_qp_supported(ctypes.byref(dims)) == 1
+    opts = _lib.dqp_opts(1e-12, 1e-10, 20, 3, 0, 0)
+    t = [dev(a) for a in (C, c, F, f, x0, lo, hi)]
+    kw = dict(dtype=torch.float64, device="cuda")
+    tau = torch.empty(B, T, nt, **kw); lam = torch.empty(B, 2 * T * m, **kw); slack = torch.empty(B, 2 * T * m, **kw)
+    nu = torch.empty(B, T * n, **kw); info = torch.empty(B, 2, dtype=torch.int32, device="cuda")
+    ws = torch.empty(int(lib.dqp_mpc_qp_workspace_bytes(ctypes.byref(dims))) // 8, **kw)
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    resid = torch.empty(B, **kw)
+    rc = lib.dqp_mpc_qp_forward(ctypes.byref(dims), ctypes.byref(opts), *[P(x) for x in t], P(tau), P(lam), P(nu),
+                                P(slack), P(info), P(resid), P(ws), None, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert int(info[:, 0].abs().max()) == 0
+    assert float(resid.max()) < 1e-8, "not converged: %s" % resid.topk(4).values.tolist()
+    Ct, ct, Ft, ft, x0t = t[:5]
+    tk = tau.transpose(0, 1)                                            # (T, B, nt)
+    x, u = tk[..., :n], tk[..., n:]
+    scale = float(tk.abs().max())
+    # feasibility: dynamics, initial state, bounds (with the slacks)
+    dyn = (Ft @ tk[:-1].unsqueeze(-1)).squeeze(-1) + ft - x[1:]
+    assert float(dyn.abs().max()) < 1e-8 * max(1.0, scale)
+    assert float((x[0] - x0t).abs().max()) < 1e-9
+    lu, ll = lam[:, :T * m].reshape(B, T, m).transpose(0, 1), lam[:, T * m:].reshape(B, T, m).transpose(0, 1)
+    su, sl = slack[:, :T * m].reshape(B, T, m).transpose(0, 1), slack[:, T * m:].reshape(B, T, m).transpose(0, 1)
+    assert float((u - dev(hi) + su).abs().max()) < 1e-8 and float((-u + dev(lo) + sl).abs().max()) < 1e-8
+    assert float(lam.min()) > 0 and float(slack.min()) > 0
+    assert float((lam * slack).max()) < 1e-8
+    # stationarity per knot: C tau + c + [0; lu - ll] + F' nu_t - [nu_{t-1}; 0] (+ [nu_init; 0] at t = 0)
+    nuk = nu.reshape(B, T, n).transpose(0, 1)
+    g = (Ct @ tk.unsqueeze(-1)).squeeze(-1) + ct
+    g[..., n:] += lu - ll
+    g[:-1] += (Ft.transpose(-1, -2) @ nuk[:-1].unsqueeze(-1)).squeeze(-1)
+    g[1:, :, :n] -= nuk[:-1]
+    g[0, :, :n] += nuk[-1]
+    assert float(g.abs().max()) < 1e-7 * max(1.0, float(nu.abs().max()))
