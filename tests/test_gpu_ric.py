@@ -170,3 +170,23 @@ def test_config4_size_kkt_properties():
     g[1:, :, :n] -= nuk[:-1]
     g[0, :, :n] += nuk[-1]
     assert float(g.abs().max()) < 1e-7 * max(1.0, float(nu.abs().max()))
+
+
+@pytest.mark.parametrize("name,T", [("RIC_n12_m4_T6_b4", 6), ("RIC_n12_m4_T10_b3", 10)])
+@pytest.mark.parametrize("tag,kw", [("single", dict(single_qp_solve=True)), ("sqp", dict(qp_iter=3))])
+def test_mpc_mirror_vs_reference_n12_m4(name, T, tag, kw):
+    """qp_wrapper.MPC end to end at n_state 12, n_ctrl 4 (the QP is nz = 96 / 160: beyond every dense
+    kernel, served by the stage-wise kernels) against the reference's own qp_wrapper.MPC outputs
+    (tests/golden/make_golden_ric.py): x, u rtol 1e-6 / atol 1e-8, gradients rtol 1e-4 / atol 1e-6."""
+    from diff_qp_mpc_amd.qp_wrapper import MPC, QuadCost, LinDx
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    B, n, m = g["in_x0"].shape[0], 12, 4
+    C, c, F, f, x0 = [dev(g["in_" + k], grad=True) for k in ("C", "c", "F", "f", "x0")]
+    mpc = MPC(n, m, T, u_lower=dev(g["in_u_lower"]), u_upper=dev(g["in_u_upper"]), n_batch=B, verbose=-1, **kw)
+    x, u = mpc(x0, QuadCost(C, c), LinDx(F, f), None)
+    np.testing.assert_allclose(x.detach().cpu().numpy(), g["%s_x" % tag], **ZT)
+    np.testing.assert_allclose(u.detach().cpu().numpy(), g["%s_u" % tag], **ZT)
+    (x.sum() + 2.0 * u.sum()).backward()
+    for k, t in (("C", C), ("c", c), ("F", F), ("f", f), ("x0", x0)):
+        got = t.grad.cpu().numpy() if t.grad is not None else np.zeros(t.shape)
+        np.testing.assert_allclose(got, g["%s_d%s" % (tag, k)], err_msg="%s d%s" % (tag, k), **GT)
