@@ -42,7 +42,7 @@ DQP_MAX_DIM = 64
 # every symbol include/dqp.h declares
 SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termination_bytes",
            "dqp_qp_forward", "dqp_qp_backward", "dqp_mpc_assemble", "dqp_mpc_assemble_backward",
-           "dqp_mpc_qp_supported", "dqp_mpc_qp_workspace_bytes", "dqp_mpc_qp_forward", "dqp_mpc_qp_backward", "dqp_mpc_line_search", "dqp_mpc_rollout_backward",
+           "dqp_mpc_qp_supported", "dqp_mpc_qp_workspace_bytes", "dqp_mpc_qp_termination_bytes", "dqp_mpc_qp_forward", "dqp_mpc_qp_backward", "dqp_mpc_line_search", "dqp_mpc_rollout_backward",
            "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble", "dqp_al_merit",
            "dqp_al_newton_solve_bytes", "dqp_al_newton_solve",
            "dqp_al_outer_update", "dqp_al_banded_factor_bytes", "dqp_al_banded_newton_step", "dqp_al_banded_solve",
@@ -107,6 +107,8 @@ def load():
     lib.dqp_mpc_qp_supported.argtypes = [ctypes.POINTER(dqp_mpc_dims)]
     lib.dqp_mpc_qp_workspace_bytes.restype = ctypes.c_size_t
     lib.dqp_mpc_qp_workspace_bytes.argtypes = [ctypes.POINTER(dqp_mpc_dims)]
+    lib.dqp_mpc_qp_termination_bytes.restype = ctypes.c_size_t
+    lib.dqp_mpc_qp_termination_bytes.argtypes = [ctypes.POINTER(dqp_mpc_dims), ctypes.POINTER(dqp_opts)]
     lib.dqp_mpc_qp_forward.restype = ctypes.c_int
     lib.dqp_mpc_qp_forward.argtypes = [ctypes.POINTER(dqp_mpc_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 16
     lib.dqp_mpc_qp_backward.restype = ctypes.c_int

@@ -102,6 +102,8 @@ bool ric_supported(int n_state, int n_ctrl);
 long long ric_workspace_doubles(int n_state, int n_ctrl, int T);
 int ric_forward(const KParams &P, void *stream);      // 1: no kernel for this (n, m)
 int ric_backward(const KParams &P, void *stream);
+int ric_snapshot_doubles(int n_state, int n_ctrl, int T);   // iterate snapshot of the batch rule's finish pass
+int ric_finish(const KParams &P, void *stream);
 // backward restarted from the context r16n_forward left in P.workspace (DQP_FLAG_BACKWARD_CTX)
 int r16n_backward(const KParams &P, void *stream);
 

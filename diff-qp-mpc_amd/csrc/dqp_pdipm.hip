@@ -873,6 +873,20 @@ static size_t mpc_workspace_doubles(const KParams &P, int kind)
     return (size_t)((P.B + 3) / 4 * 4) * (size_t)ric_workspace_doubles(P.mn, P.mm, P.mT);
 }
 
+static int mpc_snapshot_doubles(const KParams &P, int kind)
+{
+    return kind == MPC_R16N ? r16n_snapshot_doubles(P.N, P.M, P.E) : ric_snapshot_doubles(P.mn, P.mm, P.mT);
+}
+
+__attribute__((visibility("default"))) size_t dqp_mpc_qp_termination_bytes(const dqp_mpc_dims *md, const dqp_opts *o)
+{
+    KParams P = {};
+    size_t lds = 0;
+    int kind;
+    if (!o || !(o->flags & DQP_FLAG_BATCH_TERMINATION) || mpc_params(md, o, P, lds, kind) != DQP_OK || md->nbatch <= 0) return 0;
+    return term_bytes(P.B, P.maxIter, mpc_snapshot_doubles(P, kind));
+}
+
 __attribute__((visibility("default"))) int dqp_mpc_qp_supported(const dqp_mpc_dims *md)
 {
     KParams P = {};
@@ -912,12 +926,12 @@ dqp_mpc_qp_forward(const dqp_mpc_dims *md, const dqp_opts *opts, const double *C
     if (!(P.flags & DQP_FLAG_BATCH_TERMINATION)) return run(P);
     if (!termination || P.maxIter > 64) return DQP_ERR_BAD_ARG;
     P.eps = opts ? opts->eps : 1e-12;
-    term_bind_pass1(P, termination, kind == MPC_R16N ? r16n_snapshot_doubles(P.N, P.M, P.E) : 0);
+    term_bind_pass1(P, termination, mpc_snapshot_doubles(P, kind));
     if ((rc = run(P)) != DQP_OK) return rc;
     if (P.flags & DQP_FLAG_HISTORY_ONLY) return DQP_OK;
     if ((rc = term_decide(P, termination, stream)) != DQP_OK) return rc;
     term_bind_pass2(P, termination);
-    return run(P);
+    return kind == MPC_R16N ? r16n_forward(P, stream) : ric_finish(P, stream);
 }
 
 __attribute__((visibility("default"))) int

@@ -79,9 +79,11 @@ template <class C> struct Ctx {
     bool xl, ul, live;              // lane holds a state row / a control row / a real problem
     int a;                          // control index of a control lane (0 otherwise)
     double uu, ulo;                 // bounds of this lane's control
-    __device__ const double *Crow(int t) const { return P.mC + (((long long)t * P.B + qp) * C::NT + (r < C::NT ? r : 0)) * C::NT; }
-    __device__ const double *Frow(int t) const { return P.mF + (((long long)t * P.B + qp) * C::NX + (xl ? r : 0)) * C::NT; }
-    __device__ const double *Fmat(int t) const { return P.mF + ((long long)t * P.B + qp) * C::NX * C::NT; }
+    // the inputs never alias the workspace: restrict-qualified so that their loads may be hoisted above
+    // the workspace stores of the previous knot
+    __device__ const double *__restrict__ Crow(int t) const { return P.mC + (((long long)t * P.B + qp) * C::NT + (r < C::NT ? r : 0)) * C::NT; }
+    __device__ const double *__restrict__ Frow(int t) const { return P.mF + (((long long)t * P.B + qp) * C::NX + (xl ? r : 0)) * C::NT; }
+    __device__ const double *__restrict__ Fmat(int t) const { return P.mF + ((long long)t * P.B + qp) * C::NX * C::NT; }
 };
 
 // y[r] = sum_c row[c] * v[c]  (row = this lane's matrix row, v distributed)
@@ -107,7 +109,7 @@ __device__ __forceinline__ void residuals(const Ctx<C> &K, double &nx2, double &
     for (int t = 0; t < T; ++t) {
         const double tau = r < NT ? w[L.X + t * NT + r] : 0.0;
         double crow[NT];
-        const double *cp = K.Crow(t);
+        const double *__restrict__ cp = K.Crow(t);
 #pragma unroll
         for (int c = 0; c < NT; ++c) crow[c] = cp[c];
         double rx = mv_row<NT>(crow, tau) + (r < NT ? K.P.mc[((long long)t * K.P.B + K.qp) * NT + r] : 0.0);
@@ -122,13 +124,13 @@ __device__ __forceinline__ void residuals(const Ctx<C> &K, double &nx2, double &
         }
         if (t < T - 1) {
             const double yt = K.xl ? w[L.Y + t * NX + r] : 0.0;
-            const double *fm = K.Fmat(t);
+            const double *__restrict__ fm = K.Fmat(t);
             double acc = 0.0;                        // (F' y)[r] = sum_i F[i][r] y[i]
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc = fma(r < NT ? fm[i * NT + r] : 0.0, rb(yt, i), acc);
             rx += acc;
             double frow[NT];
-            const double *fp = K.Frow(t);
+            const double *__restrict__ fp = K.Frow(t);
 #pragma unroll
             for (int c = 0; c < NT; ++c) frow[c] = fp[c];
             const double fx = mv_row<NT>(frow, tau);
@@ -167,7 +169,7 @@ __device__ __forceinline__ bool factor(const Ctx<C> &K, bool unit, bool clampd)
     bool ok = true;
     for (int t = T - 1; t >= 0; --t) {
         double H[NT];
-        const double *cp = K.Crow(t);
+        const double *__restrict__ cp = K.Crow(t);
 #pragma unroll
         for (int c = 0; c < NT; ++c) H[c] = r < NT ? cp[c] : (r == c ? 1.0 : 0.0);
         if (K.ul) {
@@ -183,7 +185,7 @@ __device__ __forceinline__ bool factor(const Ctx<C> &K, bool unit, bool clampd)
         }
         if (t < T - 1) {
             double frow[NT], fcol[NX], PF[NT];
-            const double *fp = K.Frow(t), *fm = K.Fmat(t);
+            const double *__restrict__ fp = K.Frow(t), *__restrict__ fm = K.Fmat(t);
 #pragma unroll
             for (int c = 0; c < NT; ++c) frow[c] = K.xl ? fp[c] : 0.0;
 #pragma unroll
@@ -272,25 +274,26 @@ __device__ __forceinline__ void sweep_back(const Ctx<C> &K, double musig)
     const int r = K.r, T = K.T;
     double *w = K.w;
     const Lay &L = K.L;
+    const double *__restrict__ fac = w + L.FAC;        // read-only during the sweeps: loads may pass the stores
     double pn = 0.0;
     for (int t = T - 1; t >= 0; --t) {
         double q, e;
         stage_rhs<C, MODE>(K, t, musig, q, e);
         double h = q;
         if (t < T - 1) {
-            const double *pr = w + L.FAC + ((long long)(t + 1) * NT + (K.xl ? r : 0)) * NT;
+            const double *__restrict__ pr = fac + ((long long)(t + 1) * NT + (K.xl ? r : 0)) * NT;
             double v = pn;
             if (MODE == INIT || MODE == AFFINE) {
 #pragma unroll
                 for (int c = 0; c < NX; ++c) v = fma(K.xl ? pr[c] : 0.0, rb(e, c), v);
             }
-            const double *fm = K.Fmat(t);
+            const double *__restrict__ fm = K.Fmat(t);
             double acc = 0.0;
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc = fma(r < NT ? fm[i * NT + r] : 0.0, rb(v, i), acc);
             h += acc;
         }
-        const double *lr = w + L.FAC + ((long long)t * NT + (r < NT ? r : 0)) * NT;
+        const double *__restrict__ lr = fac + ((long long)t * NT + (r < NT ? r : 0)) * NT;
         const double rd = K.ul ? lr[0] : 0.0;
 #pragma unroll
         for (int j = NX; j < NT; ++j) {
@@ -313,6 +316,7 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K, double musig)
     const int r = K.r, T = K.T;
     double *w = K.w;
     const Lay &L = K.L;
+    const double *__restrict__ fac = w + L.FAC, *__restrict__ pvv = w + L.PV, *__restrict__ ybv = w + L.YB;
     double ratio = INFINITY;
     // dx_0 = -ry_init
     double dx = 0.0;
@@ -321,8 +325,8 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K, double musig)
         else if (MODE == AFFINE) dx = -w[L.RY + (T - 1) * NX + r];
     }
     {   // dy_init = -(P_0 dx_0 + p_0)
-        const double *pr = w + L.FAC + (long long)(K.xl ? r : 0) * NT;
-        double v = K.xl ? w[L.PV + r] : 0.0;
+        const double *__restrict__ pr = fac + (long long)(K.xl ? r : 0) * NT;
+        double v = K.xl ? pvv[r] : 0.0;
 #pragma unroll
         for (int c = 0; c < NX; ++c) v = fma(K.xl ? pr[c] : 0.0, rb(dx, c), v);
         if (K.xl) {
@@ -331,12 +335,12 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K, double musig)
         }
     }
     for (int t = 0; t < T; ++t) {
-        const double *lr = w + L.FAC + ((long long)t * NT + (r < NT ? r : 0)) * NT;
+        const double *__restrict__ lr = fac + ((long long)t * NT + (r < NT ? r : 0)) * NT;
         double lrow[NU];
 #pragma unroll
         for (int b = 0; b < NU; ++b) lrow[b] = r < NT ? lr[NX + b] : 0.0;
         const double rd = K.ul ? lr[0] : 0.0;
-        double zz = K.ul ? w[L.YB + t * NU + K.a] : 0.0;
+        double zz = K.ul ? ybv[t * NU + K.a] : 0.0;
 #pragma unroll
         for (int b = 0; b < NU; ++b) {
             const double wb = row_sum(K.xl ? lrow[b] * dx : 0.0);        // (Lxu' dx)[b]
@@ -381,14 +385,14 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K, double musig)
         }
         if (t < T - 1) {
             double frow[NT];
-            const double *fp = K.Frow(t);
+            const double *__restrict__ fp = K.Frow(t);
 #pragma unroll
             for (int c = 0; c < NT; ++c) frow[c] = K.xl ? fp[c] : 0.0;
             double q, e;
             stage_rhs<C, MODE>(K, t, musig, q, e);
             const double dxn = mv_row<NT>(frow, dtau) + e;
-            const double *pr = w + L.FAC + ((long long)(t + 1) * NT + (K.xl ? r : 0)) * NT;
-            double v = K.xl ? w[L.PV + (t + 1) * NX + r] : 0.0;
+            const double *__restrict__ pr = fac + ((long long)(t + 1) * NT + (K.xl ? r : 0)) * NT;
+            double v = K.xl ? pvv[(t + 1) * NX + r] : 0.0;
 #pragma unroll
             for (int c = 0; c < NX; ++c) v = fma(K.xl ? pr[c] : 0.0, rb(dxn, c), v);
             if (K.xl) {
@@ -402,23 +406,45 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K, double musig)
 }
 
 // element-wise helpers over the constraint arrays (length 2 T NU, lanes strided)
+// element-wise helpers over per-QP arrays, lanes strided, four independent loads in flight per lane
+// (a plain `for (i = r; i < n; i += 16) dst[i] = src[i]` waits out one memory latency per element:
+// nothing tells the compiler that dst and src are different regions of the workspace)
+__device__ __forceinline__ void ew_copy(double *__restrict__ dst, const double *__restrict__ src, int n, int r)
+{
+    int i = r;
+    for (; i + 48 < n; i += 64) {
+        const double a = src[i], b = src[i + 16], c = src[i + 32], d = src[i + 48];
+        dst[i] = a; dst[i + 16] = b; dst[i + 32] = c; dst[i + 48] = d;
+    }
+    for (; i < n; i += 16) dst[i] = src[i];
+}
+__device__ __forceinline__ void ew_axpy(double *__restrict__ y, const double *__restrict__ x, double alpha, int n, int r)
+{
+    int i = r;
+    for (; i + 48 < n; i += 64) {
+        const double a = x[i], b = x[i + 16], c = x[i + 32], d = x[i + 48];
+        const double ya = y[i], yb = y[i + 16], yc = y[i + 32], yd = y[i + 48];
+        y[i] = fma(alpha, a, ya); y[i + 16] = fma(alpha, b, yb); y[i + 32] = fma(alpha, c, yc); y[i + 48] = fma(alpha, d, yd);
+    }
+    for (; i < n; i += 16) y[i] = fma(alpha, x[i], y[i]);
+}
+
+// the iterate (X, Y, SU, SL, ZU, ZL: contiguous at the head of the layout) -> the best-iterate arrays,
+// and, under the batch rule, -> this iteration's snapshot (the finish pass picks the right one)
 template <class C>
-__device__ __forceinline__ void copy_best(const Ctx<C> &K)
+__device__ __forceinline__ void copy_best(const Ctx<C> &K, double *snap)
 {
     constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
     double *w = K.w;
     const Lay &L = K.L;
     const int T = K.T, r = K.r;
-    for (int i = r; i < T * NT; i += 16) w[L.BX + i] = w[L.X + i];
-    for (int i = r; i < T * NX; i += 16) w[L.BY + i] = w[L.Y + i];
-    for (int i = r; i < T * NU; i += 16) {
-        w[L.BSU + i] = w[L.SU + i]; w[L.BSL + i] = w[L.SL + i];
-        w[L.BZU + i] = w[L.ZU + i]; w[L.BZL + i] = w[L.ZL + i];
-    }
+    const int len = T * (NT + NX + 4 * NU);
+    if (snap && K.live) ew_copy(snap, w, len, r);
+    ew_copy(w + L.BX, w + L.X, len, r);          // BX, BY, BSU, BSL, BZU, BZL mirror X .. ZL
 }
 
 template <class C>
-__global__ __launch_bounds__(64) void forward_kernel(KParams P, int T)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void forward_kernel(KParams P, int T)
 {
     constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
     const int lane = threadIdx.x, r = lane & 15;
@@ -448,8 +474,8 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P, int T)
     sweep_back<C, INIT>(K, 0.0);
     sweep_fwd<C, INIT>(K, 0.0);
     {
-        for (int i = r; i < T * NT; i += 16) w[L.X + i] = w[L.DX + i];
-        for (int i = r; i < T * NX; i += 16) w[L.Y + i] = w[L.DY + i];
+        ew_copy(w + L.X, w + L.DX, T * NT, r);
+        ew_copy(w + L.Y, w + L.DY, T * NX, r);
         double ms = INFINITY, mz = INFINITY;
         for (int i = r; i < T * NU; i += 16) {
             ms = fmin(ms, fmin(w[L.SU + i], w[L.SL + i]));
@@ -473,7 +499,10 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P, int T)
         const double resid = sqrt(nz2) + sqrt(ny2) + sqrt(nx2) + nineq * mu;
         if (!done) {
             iters = it + 1;
-            if (!have_best || resid < best) { nNot = 0; have_best = true; best = resid; copy_best<C>(K); }
+            if (!have_best || resid < best) {
+                nNot = 0; have_best = true; best = resid;
+                copy_best<C>(K, P.snap ? P.snap + ((long long)it * P.B + qp) * (long long)(T * (NT + NX + 4 * NU)) : nullptr);
+            }
             else nNot += 1;
             if (batch) {
                 if (P.hist && r == 0 && live) hist_put(P, qp, it, resid, mu);
@@ -501,18 +530,12 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P, int T)
         sweep_back<C, CORRECTOR>(K, mu * sig);
         const double rc = row_min(sweep_fwd<C, CORRECTOR>(K, mu * sig));
         const double alpha = fmin(0.999 * rc, 1.0);
-        if (!done) {
-            for (int i = r; i < T * NT; i += 16) w[L.X + i] += alpha * w[L.DX + i];
-            for (int i = r; i < T * NX; i += 16) w[L.Y + i] += alpha * w[L.DY + i];
-            for (int i = r; i < T * NU; i += 16) {
-                w[L.SU + i] += alpha * w[L.DSU + i]; w[L.SL + i] += alpha * w[L.DSL + i];
-                w[L.ZU + i] += alpha * w[L.DZU + i]; w[L.ZL + i] += alpha * w[L.DZL + i];
-            }
-        }
+        if (!done)          // X .. ZL and DX .. DZL are laid out alike: one axpy over the whole iterate
+            ew_axpy(w + L.X, w + L.DX, alpha, T * (NT + NX + 4 * NU), r);
     }
     if (P.hist && r == 0 && live) hist_fill(P, qp, iters);
     if (!have_best) {       // max_iter == 0 cannot happen (checked on the host); kept for symmetry
-        copy_best<C>(K);
+        copy_best<C>(K, nullptr);
     }
     // ---- outputs in the reference's orderings
     if (live) {
@@ -587,6 +610,36 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P, int T)
     if (r == 0 && P.info) { P.info[2 * qp] = status; P.info[2 * qp + 1] = 0; }
 }
 
+// Pass 2 of the batch-coupled rule (dqp_term.hip) when pass 1 kept its improving iterates: a flagged
+// problem's outputs are rewritten from the snapshot of its best iteration before the stop -- a copy.
+// One wavefront per problem; sizes at run time.
+__global__ __launch_bounds__(64) void finish_kernel(KParams P, int T, int nx, int nu)
+{
+    const long long qp = blockIdx.x;
+    if (P.cap[TERM_HDR + qp] == 0) return;
+    const int cap = min(P.maxIter, P.cap[0]);
+    const double2 *h = reinterpret_cast<const double2 *>(P.histIn) + qp;
+    double best = h[0].x;
+    int arg = 0;
+    for (int it = 1; it < cap; ++it) {
+        const double v = h[(long long)it * P.B].x;
+        if (v < best) { best = v; arg = it; }
+    }
+    const int nt = nx + nu, nz = T * nt, neq = T * nx, hm = T * nu;
+    const double *sp = P.snap + ((long long)arg * P.B + qp) * (long long)(nz + neq + 4 * hm);
+    const int lane = threadIdx.x;
+    for (int i = lane; i < nz; i += 64) P.zhat[qp * nz + i] = sp[i];
+    for (int i = lane; i < neq; i += 64) P.nu[qp * neq + i] = sp[nz + i];
+    for (int i = lane; i < hm; i += 64) {
+        P.slack[qp * 2 * hm + i] = sp[nz + neq + i];            P.slack[qp * 2 * hm + hm + i] = sp[nz + neq + hm + i];
+        P.lam[qp * 2 * hm + i] = sp[nz + neq + 2 * hm + i];     P.lam[qp * 2 * hm + hm + i] = sp[nz + neq + 3 * hm + i];
+    }
+    if (lane == 0) {
+        if (P.info) P.info[2 * qp + 1] = cap;
+        if (P.best_resid) P.best_resid[qp] = best;
+    }
+}
+
 template <class C, class Kern> int launch(Kern kernel, const KParams &P, int T, void *stream)
 {
     const int blocks = (P.B + 3) / 4;
@@ -618,6 +671,14 @@ int ric_forward(const KParams &P, void *stream)
     DQP_RIC_SIZES
 #undef X
     return 1;
+}
+
+int ric_snapshot_doubles(int n, int m, int T) { return ric_supported(n, m) ? T * (2 * n + 5 * m) : 0; }
+
+int ric_finish(const KParams &P, void *stream)
+{
+    hipLaunchKernelGGL(ric::finish_kernel, dim3(P.B), dim3(64), 0, (hipStream_t)stream, P, P.mT, P.mn, P.mm);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
 int ric_backward(const KParams &P, void *stream)

@@ -165,8 +165,7 @@ class _MPCQP(Function):
         info = torch.empty(B, 2, dtype=torch.int32, device=dev)
         resid = torch.empty(B, **kw)
         ws = torch.empty(int(lib.dqp_mpc_qp_workspace_bytes(ctypes.byref(dims))) // 8, **kw)
-        qd = _lib.dqp_dims(B, T * nt, 2 * T * n_ctrl, T * n_state, 0, 0, 0, 0, 0, 0)
-        tb = int(lib.dqp_termination_bytes(ctypes.byref(qd), ctypes.byref(opts)))
+        tb = int(lib.dqp_mpc_qp_termination_bytes(ctypes.byref(dims), ctypes.byref(opts)))
         term = torch.empty((tb + 7) // 8, **kw) if tb else None
         with torch.cuda.device(dev):
             rc = lib.dqp_mpc_qp_forward(ctypes.byref(dims), ctypes.byref(opts), *[_ptr(t) for t in keep],

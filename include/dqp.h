@@ -225,6 +225,9 @@ int dqp_mpc_assemble_backward(const dqp_mpc_dims *dims, const double *dQ, const 
  */
 int dqp_mpc_qp_supported(const dqp_mpc_dims *dims);
 size_t dqp_mpc_qp_workspace_bytes(const dqp_mpc_dims *dims);
+/* the `termination` buffer of dqp_mpc_qp_forward under DQP_FLAG_BATCH_TERMINATION (history, redo list and the
+ * improving iterates of pass 1, from which pass 2 finishes without solving again); 0 without the flag */
+size_t dqp_mpc_qp_termination_bytes(const dqp_mpc_dims *dims, const dqp_opts *opts);
 int dqp_mpc_qp_forward(const dqp_mpc_dims *dims, const dqp_opts *opts, const double *C, const double *c,
                        const double *F, const double *f, const double *x0, const double *u_lower,
                        const double *u_upper, double *tau, double *lam, double *nu, double *slack,

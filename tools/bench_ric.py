@@ -45,8 +45,7 @@ def timed(fn, reps=5):
 
 for mode, flag in (("batch", _lib.DQP_FLAG_BATCH_TERMINATION), ("per_problem", 0)):
     opts = _lib.dqp_opts(1e-12, 1e-10, 20, 3, flag, 0)
-    qd = _lib.dqp_dims(B, T * nt, 2 * T * m, T * n, 0, 0, 0, 0, 0, 0)
-    tb = int(lib.dqp_termination_bytes(ctypes.byref(qd), ctypes.byref(opts)))
+    tb = int(lib.dqp_mpc_qp_termination_bytes(ctypes.byref(dims), ctypes.byref(opts)))
     term = torch.empty(max(tb // 8, 1), **kw)
     def fwd():
         rc = lib.dqp_mpc_qp_forward(ctypes.byref(dims), ctypes.byref(opts), P(C), P(c), P(F), P(f), P(x0), P(lo), P(hi),
