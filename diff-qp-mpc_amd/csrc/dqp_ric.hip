@@ -233,6 +233,139 @@ __device__ __forceinline__ bool factor(const Ctx<C> &K, bool unit, bool clampd)
     return ok;
 }
 
+// ---------------------------------------------------------------------------------------------
+// One backward sweep for the three things an iteration needs from every knot before it can move:
+// the residuals of the iterate (as residuals()), the Riccati factorisation with d = z/s (as factor())
+// and the affine right-hand side pushed through it (as sweep_back<AFFINE>) -- C_t and F_t are read
+// once instead of three times (the kernel is bound by those streams).
+template <class C>
+__device__ __forceinline__ bool factor_fused(const Ctx<C> &K, double &nx2, double &nz2, double &ny2, double &sz)
+{
+    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    const int r = K.r, T = K.T;
+    double *w = K.w;
+    const Lay &L = K.L;
+    nx2 = nz2 = ny2 = sz = 0.0;
+    double Pn[NX];
+#pragma unroll
+    for (int c = 0; c < NX; ++c) Pn[c] = 0.0;
+    double pn = 0.0;
+    bool ok = true;
+    for (int t = T - 1; t >= 0; --t) {
+        // ---- loads
+        const double tau = r < NT ? w[L.X + t * NT + r] : 0.0;
+        double H[NT];
+        const double *__restrict__ cp = K.Crow(t);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) H[c] = r < NT ? cp[c] : 0.0;
+        double rx = mv_row<NT>(H, tau) + (r < NT ? K.P.mc[((long long)t * K.P.B + K.qp) * NT + r] : 0.0);
+        double q = 0.0, e = 0.0;
+        if (K.ul) {
+            const int iu = t * NU + K.a;
+            const double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
+            rx += zu - zl;
+            const double rzu = tau - K.uu + su, rzl = -tau + K.ulo + sl;
+            w[L.RZU + iu] = rzu; w[L.RZL + iu] = rzl;
+            nz2 = fma(rzu, rzu, fma(rzl, rzl, nz2));
+            sz = fma(su, zu, fma(sl, zl, sz));
+            const double du_ = zu / su, dl_ = zl / sl;
+            q = -((zu - du_ * rzu) - (zl - dl_ * rzl));
+#pragma unroll
+            for (int c = 0; c < NT; ++c) H[c] += (r == c) ? du_ + dl_ : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) H[c] = r < NT ? H[c] : (r == c ? 1.0 : 0.0);
+        double fcol[NX];
+        if (t < T - 1) {
+            double frow[NT];
+            const double *__restrict__ fp = K.Frow(t), *__restrict__ fm = K.Fmat(t);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) frow[c] = K.xl ? fp[c] : 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) fcol[i] = r < NT ? fm[i * NT + r] : 0.0;
+            const double yt = K.xl ? w[L.Y + t * NX + r] : 0.0;
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc = fma(fcol[i], rb(yt, i), acc);
+            rx += acc;
+            const double fx = mv_row<NT>(frow, tau);
+            if (K.xl) {
+                e = fx - w[L.X + (t + 1) * NT + r] + K.P.mf[((long long)t * K.P.B + K.qp) * NX + r];
+                w[L.RY + t * NX + r] = e;
+                ny2 = fma(e, e, ny2);
+            }
+            // H += F' P_{t+1} F
+            double PF[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                double a2 = 0.0;
+#pragma unroll
+                for (int c = 0; c < NX; ++c) a2 = fma(Pn[c], rb(frow[j], c), a2);
+                PF[j] = a2;
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                double a2 = H[b];
+#pragma unroll
+                for (int i = 0; i < NX; ++i) a2 = fma(fcol[i], rb(PF[b], i), a2);
+                H[b] = a2;
+            }
+        }
+        if (K.xl) {
+            if (t >= 1) rx -= w[L.Y + (t - 1) * NX + r];
+            else {
+                rx += w[L.Y + (T - 1) * NX + r];
+                const double ry = tau - K.P.mx0[K.qp * NX + r];
+                w[L.RY + (T - 1) * NX + r] = ry;
+                ny2 = fma(ry, ry, ny2);
+            }
+        }
+        if (r < NT) { w[L.RX + t * NT + r] = rx; nx2 = fma(rx, rx, nx2); }
+        q += rx;
+        // ---- affine right-hand side: h = q + F'(P_{t+1} e + p_{t+1})
+        double h = q;
+        if (t < T - 1) {
+            double v = pn;
+#pragma unroll
+            for (int c = 0; c < NX; ++c) v = fma(Pn[c], rb(e, c), v);
+            double acc = 0.0;
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc = fma(fcol[i], rb(v, i), acc);
+            h += acc;
+        }
+        // ---- partial Cholesky on the control pivots, the same elimination on h
+        double rdj_keep = 0.0;
+#pragma unroll
+        for (int j = NX; j < NT; ++j) {
+            const double pj = rb(H[j], j);
+            if (!(pj > 0.0)) ok = false;
+            const double rdj = frsqrt(pj > 0.0 ? pj : 1.0);
+            const double lij = H[j] * rdj;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                if (c >= NX && c <= j) continue;
+                H[c] = fma(-lij, rb(lij, c), H[c]);
+            }
+            H[j] = lij;
+            if (r == j) rdj_keep = rdj;
+            const double hj = rb(h, j) * rdj;
+            h = (r == j) ? hj : ((r < NX || (r > j && r < NT)) ? fma(-lij, hj, h) : h);
+        }
+        if (K.ul) H[0] = rdj_keep;
+        if (r < NT) {
+            double *o = w + L.FAC + ((long long)t * NT + r) * NT;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) o[c] = H[c];
+        }
+        if (K.xl) w[L.PV + t * NX + r] = h;
+        if (K.ul) w[L.YB + t * NU + K.a] = h;
+        pn = K.xl ? h : 0.0;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) Pn[c] = K.xl ? H[c] : 0.0;
+    }
+    return ok;
+}
+
 // right-hand side of one stage for the four uses of the solver: q_t[r] (= -rhs1) and e_t[r]
 template <class C, int MODE>
 __device__ __forceinline__ void stage_rhs(const Ctx<C> &K, int t, double musig, double &q, double &e)
@@ -493,7 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int nNot = 0, iters = 0;
     for (int it = 0; it < maxIter; ++it) {
         double nx2, nz2, ny2, sz;
-        residuals<C>(K, nx2, nz2, ny2, sz);
+        const bool pd = factor_fused<C>(K, nx2, nz2, ny2, sz);      // residuals + factorisation + affine rhs
         nx2 = row_sum(nx2); nz2 = row_sum(nz2); ny2 = row_sum(ny2); sz = row_sum(sz);
         const double mu = fabs(sz / nineq);
         const double resid = sqrt(nz2) + sqrt(ny2) + sqrt(nx2) + nineq * mu;
@@ -513,9 +646,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         if (__builtin_amdgcn_ballot_w64(!done) == 0) break;
 
-        if (!factor<C>(K, false, false) && status == DQP_STATUS_OK) status = DQP_STATUS_Q_NOT_PD;
+        if (!pd && status == DQP_STATUS_OK) status = DQP_STATUS_Q_NOT_PD;
         // affine direction and its step (batch.py:147-163)
-        sweep_back<C, AFFINE>(K, 0.0);
         double ra = row_min(sweep_fwd<C, AFFINE>(K, 0.0));
         const double alpha_a = fmin(ra, 1.0);
         double t3 = 0.0;
