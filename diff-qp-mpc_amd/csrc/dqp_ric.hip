@@ -96,64 +96,6 @@ template <int N> __device__ __forceinline__ double mv_row(const double (&row)[N]
 }
 
 // ---------------------------------------------------------------------------------------------
-// residuals of the iterate in X, Y, S*, Z* (batch.py:93-108): rx = C tau + c + G'z + A'y,
-// rz = G tau + s - h, ry = A tau - b; returns (||rx||^2, ||rz||^2, ||ry||^2, s'z) partials (lane-local)
-template <class C>
-__device__ __forceinline__ void residuals(const Ctx<C> &K, double &nx2, double &nz2, double &ny2, double &sz)
-{
-    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
-    const int r = K.r, T = K.T;
-    double *w = K.w;
-    const Lay &L = K.L;
-    nx2 = nz2 = ny2 = sz = 0.0;
-    for (int t = 0; t < T; ++t) {
-        const double tau = r < NT ? w[L.X + t * NT + r] : 0.0;
-        double crow[NT];
-        const double *__restrict__ cp = K.Crow(t);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) crow[c] = cp[c];
-        double rx = mv_row<NT>(crow, tau) + (r < NT ? K.P.mc[((long long)t * K.P.B + K.qp) * NT + r] : 0.0);
-        if (K.ul) {
-            const int iu = t * NU + K.a;
-            const double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
-            rx += zu - zl;
-            const double rzu = tau - K.uu + su, rzl = -tau + K.ulo + sl;
-            w[L.RZU + iu] = rzu; w[L.RZL + iu] = rzl;
-            nz2 = fma(rzu, rzu, fma(rzl, rzl, nz2));
-            sz = fma(su, zu, fma(sl, zl, sz));
-        }
-        if (t < T - 1) {
-            const double yt = K.xl ? w[L.Y + t * NX + r] : 0.0;
-            const double *__restrict__ fm = K.Fmat(t);
-            double acc = 0.0;                        // (F' y)[r] = sum_i F[i][r] y[i]
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc = fma(r < NT ? fm[i * NT + r] : 0.0, rb(yt, i), acc);
-            rx += acc;
-            double frow[NT];
-            const double *__restrict__ fp = K.Frow(t);
-#pragma unroll
-            for (int c = 0; c < NT; ++c) frow[c] = fp[c];
-            const double fx = mv_row<NT>(frow, tau);
-            if (K.xl) {
-                const double ry = fx - w[L.X + (t + 1) * NT + r] + K.P.mf[((long long)t * K.P.B + K.qp) * NX + r];
-                w[L.RY + t * NX + r] = ry;
-                ny2 = fma(ry, ry, ny2);
-            }
-        }
-        if (K.xl) {
-            if (t >= 1) rx -= w[L.Y + (t - 1) * NX + r];
-            else {
-                rx += w[L.Y + (T - 1) * NX + r];
-                const double ry = tau - K.P.mx0[K.qp * NX + r];
-                w[L.RY + (T - 1) * NX + r] = ry;
-                ny2 = fma(ry, ry, ny2);
-            }
-        }
-        if (r < NT) { w[L.RX + t * NT + r] = rx; nx2 = fma(rx, rx, nx2); }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // backward Riccati sweep on the matrices; d = z/s from the iterate (unit: d = 1, clampd: the
 // reference's backward clamps, qp.py:131-134).  Returns false if a control pivot is not positive.
 template <class C>
@@ -235,8 +177,9 @@ __device__ __forceinline__ bool factor(const Ctx<C> &K, bool unit, bool clampd)
 
 // ---------------------------------------------------------------------------------------------
 // One backward sweep for the three things an iteration needs from every knot before it can move:
-// the residuals of the iterate (as residuals()), the Riccati factorisation with d = z/s (as factor())
-// and the affine right-hand side pushed through it (as sweep_back<AFFINE>) -- C_t and F_t are read
+// the residuals of the iterate (batch.py:93-108: rx = C tau + c + G'z + A'y, rz = G tau + s - h,
+// ry = A tau - b), the Riccati factorisation with d = z/s (as factor()) and the affine right-hand side
+// pushed through it (as sweep_back<AFFINE>) -- C_t and F_t are read
 // once instead of three times (the kernel is bound by those streams).
 template <class C>
 __device__ __forceinline__ bool factor_fused(const Ctx<C> &K, double &nx2, double &nz2, double &ny2, double &sz)
