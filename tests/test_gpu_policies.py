@@ -77,3 +77,38 @@ def test_train_step_lowers_the_loss(solver_type):
         assert np.isfinite(losses[-1])
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in policy.model.parameters())
     assert losses[-1] < losses[0]
+
+
+def test_config5_shard_training_step_runs_at_size():
+    """BASELINE config 5 on one GPU's share of the batch: DEQMPCPolicy on the cartpole-2 device model
+    (n 6, m 1, T 5, dt 0.03), B = 8192 = 65536 / 8 trajectories, deq_iter 6: two optimiser steps; finite
+    loss, every DEQLayer parameter gets a finite gradient, the MPC iterates respect x_0 = x0 and the
+    control bounds.  (Values are pinned at small B by the cartpole-2 AL fixture and the pendulum policy
+    fixture; this is the size check.)"""
+    from diff_qp_mpc_amd import policies
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    B, T, deq_iter = 8192, 5, 6
+    dyn = DeviceDynamics("cartpole2l", dt=0.03)
+    nx, nu, ub = dyn.n_state, dyn.n_ctrl, 250.0
+    env = types.SimpleNamespace(nx=nx, nu=nu, nq=nx // 2, dt=dyn.dt, dynamics=dyn, dynamics_derivatives=dyn.jac,
+                                action_space=types.SimpleNamespace(high=np.array([ub]), low=np.array([-ub])))
+    args = argparse.Namespace(T=T, nq=nx // 2, hdim=128, layer_type="mlp", deq_out_type=1, policy_out_type=1,
+                              deq_iter=deq_iter, solver_type="al", qp_iter=1, eps=1e-2, warm_start=True, bsz=B,
+                              Q=torch.ones(nx), R=1e-2 * torch.ones(nu), dtype="double", device="cuda")
+    torch.manual_seed(0)
+    policy = policies.DEQMPCPolicy(args, env)
+    opt = torch.optim.Adam(policy.model.parameters(), lr=1e-4)
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    x = torch.rand(B, nx, device="cuda", generator=gen) - 0.5
+    gs = x[:, None, :] * torch.linspace(1, 0, T, device="cuda")[None, :, None]
+    ga = torch.zeros(B, T, nu, device="cuda")
+    mask = torch.ones(B, T, device="cuda")
+    for _ in range(2):
+        loss, loss_end, dyn_res = policies.train_step(policy, opt, x, gs, ga, mask)
+        assert np.isfinite(float(loss)) and np.isfinite(float(loss_end))
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in policy.model.parameters())
+    trajs, _ = policy(x, gs, ga, mask, qp_solve=True)
+    assert len(trajs) == deq_iter
+    for net, xs, us in trajs:
+        assert bool(torch.isfinite(xs).all()) and bool(torch.isfinite(us).all())
+        assert float((xs[:, 0] - x).abs().max()) < 1e-5
