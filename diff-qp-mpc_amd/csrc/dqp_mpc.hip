@@ -174,9 +174,9 @@ __device__ __forceinline__ void ls_step(const double *xs, const double *us, doub
     for (int k = 0; k < Map::NX; ++k) out[k] = o[k];
 }
 
-__device__ __forceinline__ double stage_cost(const LsP &P, long long b, int t, const double *xs, const double *us)
+__device__ __forceinline__ double stage_cost(const LsP &P, long long b, int t, const double *xs, const double *us, int n, int m)
 {
-    const int n = P.n, nt = n + P.m;
+    const int nt = n + m;
     if (!P.C) return 0.0;                     // rollout only (dqp_mpc_line_search with C == NULL)
     const double *Ct = P.C + ((long long)t * P.B + b) * nt * nt, *ct = P.c + ((long long)t * P.B + b) * nt;
     double acc = 0.0;
@@ -189,21 +189,31 @@ __device__ __forceinline__ double stage_cost(const LsP &P, long long b, int t, c
     return acc;
 }
 
+// One instantiation per dynamics (the LinDx form with run-time sizes, one per registered model with its
+// sizes as constants): a single kernel with a run-time switch over the models takes the registers and
+// scratch of the largest of them (the 12-state quadrotor) for every model.
+struct LinStep { static constexpr bool LIN = true, FIXED = false; static constexpr int NX = LS_MAXN, NU = LS_MAXM; };
+// LinDx at a compile-time size: loops unroll, the state lives in registers instead of scratch
+template <int N, int M_> struct LinStepT { static constexpr bool LIN = true, FIXED = true; static constexpr int NX = N, NU = M_; };
+template <class Map> struct ModelStep { static constexpr bool LIN = false, FIXED = true; static constexpr int NX = Map::NX, NU = Map::NU; using M = Map; };
+#define DQP_LIN_SIZES X(3, 3) X(3, 1) X(4, 1) X(6, 1) X(2, 1) X(4, 2) X(3, 2) X(12, 4)
+
+template <class S>
 __global__ __launch_bounds__(64) void line_search_kernel(LsP P)
 {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
-    const int n = P.n, m = P.m, T = P.T, nt = n + m;
+    const int n = S::FIXED ? S::NX : P.n, m = S::FIXED ? S::NU : P.m, T = P.T, nt = n + m;
     double cost_here = 0.0;
     for (int t = 0; t < T && P.C; ++t) {
-        double xs[LS_MAXN], us[LS_MAXM];
+        double xs[S::NX], us[S::NU];
         for (int i = 0; i < n; ++i) xs[i] = P.x[((long long)t * P.B + b) * n + i];
         for (int i = 0; i < m; ++i) us[i] = P.u[((long long)t * P.B + b) * m + i];
-        cost_here += stage_cost(P, b, t, xs, us);
+        cost_here += stage_cost(P, b, t, xs, us, n, m);
     }
     double alpha = 1.0, cost_try = 0.0;
     for (int round = 0; round < P.max_iter; ++round) {
-        double xs[LS_MAXN], us[LS_MAXM], nx[LS_MAXN];
+        double xs[S::NX], us[S::NU], nx[S::NX];
         for (int i = 0; i < n; ++i) xs[i] = P.x0[b * n + i];
         cost_try = 0.0;
         for (int t = 0; t < T; ++t) {
@@ -213,9 +223,9 @@ __global__ __launch_bounds__(64) void line_search_kernel(LsP P)
                 P.un[o] = us[i];
             }
             for (int i = 0; i < n; ++i) P.xn[((long long)t * P.B + b) * n + i] = xs[i];
-            cost_try += stage_cost(P, b, t, xs, us);
+            cost_try += stage_cost(P, b, t, xs, us, n, m);
             if (t == T - 1) break;
-            if (P.dyn == 0) {           // LinDx: x+ = F_t [x; u] + f_t
+            if constexpr (S::LIN) {     // LinDx: x+ = F_t [x; u] + f_t
                 const double *Ft = P.F + ((long long)t * P.B + b) * n * nt, *ft = P.f + ((long long)t * P.B + b) * n;
                 for (int i = 0; i < n; ++i) {
                     double a = ft[i];
@@ -223,14 +233,7 @@ __global__ __launch_bounds__(64) void line_search_kernel(LsP P)
                     nx[i] = a;
                 }
             } else {
-                switch (P.dyn) {
-                case DQP_DYN_PENDULUM1L: ls_step<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>(xs, us, P.dt, nx); break;
-                case DQP_DYN_CARTPOLE1L: ls_step<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(xs, us, P.dt, nx); break;
-                case DQP_DYN_CARTPOLE2L: ls_step<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(xs, us, P.dt, nx); break;
-                case DQP_DYN_PENDULUM_EULER: ls_step<dqp::dyn::PendulumEuler>(xs, us, P.dt, nx); break;
-                case DQP_DYN_REXQUADROTOR: ls_step<dqp::dyn::RexQuadrotor>(xs, us, P.dt, nx); break;
-                default: ls_step<dqp::dyn::PendulumDx>(xs, us, P.dt, nx); break;
-                }
+                ls_step<typename S::M>(xs, us, P.dt, nx);
             }
             for (int i = 0; i < n; ++i) xs[i] = nx[i];
         }
@@ -279,18 +282,19 @@ __device__ __forceinline__ void vjp_step(const double *xs, const double *us, dou
     }
 }
 
+template <class S>
 __global__ __launch_bounds__(64) void rollout_backward_kernel(RbP P)
 {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
-    const int n = P.n, m = P.m, T = P.T, nt = n + m;
-    double lam[LS_MAXN], gx[LS_MAXN], gu[LS_MAXM], xs[LS_MAXN], us[LS_MAXM];
+    const int n = S::FIXED ? S::NX : P.n, m = S::FIXED ? S::NU : P.m, T = P.T, nt = n + m;
+    double lam[S::NX], gx[S::NX], gu[S::NU], xs[S::NX], us[S::NU];
     for (int i = 0; i < n; ++i) lam[i] = P.g[((long long)(T - 1) * P.B + b) * n + i];
     if (P.du) for (int i = 0; i < m; ++i) P.du[((long long)(T - 1) * P.B + b) * m + i] = 0.0;   // last action unused
     for (int t = T - 2; t >= 0; --t) {
         for (int i = 0; i < n; ++i) xs[i] = P.x[((long long)t * P.B + b) * n + i];
         for (int i = 0; i < m; ++i) us[i] = P.u[((long long)t * P.B + b) * m + i];
-        if (P.dyn == 0) {
+        if constexpr (S::LIN) {
             const double *Ft = P.F + ((long long)t * P.B + b) * n * nt;
             for (int j = 0; j < nt; ++j) {
                 double a = 0.0;
@@ -304,14 +308,7 @@ __global__ __launch_bounds__(64) void rollout_backward_kernel(RbP P)
             }
             if (P.df) for (int i = 0; i < n; ++i) P.df[((long long)t * P.B + b) * n + i] = lam[i];
         } else {
-            switch (P.dyn) {
-            case DQP_DYN_PENDULUM1L: vjp_step<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>(xs, us, P.dt, lam, gx, gu); break;
-            case DQP_DYN_CARTPOLE1L: vjp_step<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(xs, us, P.dt, lam, gx, gu); break;
-            case DQP_DYN_CARTPOLE2L: vjp_step<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(xs, us, P.dt, lam, gx, gu); break;
-            case DQP_DYN_PENDULUM_EULER: vjp_step<dqp::dyn::PendulumEuler>(xs, us, P.dt, lam, gx, gu); break;
-            case DQP_DYN_REXQUADROTOR: vjp_step<dqp::dyn::RexQuadrotor>(xs, us, P.dt, lam, gx, gu); break;
-            default: vjp_step<dqp::dyn::PendulumDx>(xs, us, P.dt, lam, gx, gu); break;
-            }
+            vjp_step<typename S::M>(xs, us, P.dt, lam, gx, gu);
         }
         if (P.du) for (int i = 0; i < m; ++i) P.du[((long long)t * P.B + b) * m + i] = gu[i];
         for (int i = 0; i < n; ++i) lam[i] = P.g[((long long)t * P.B + b) * n + i] + gx[i];
@@ -401,7 +398,23 @@ dqp_mpc_line_search(const dqp_mpc_dims *d, int dyn_id, double dt, const double *
     P.xn = x_new; P.un = u_new; P.alpha = alpha; P.cost = cost_new;
     P.decay = decay; P.dt = dt; P.B = d->nbatch; P.n = d->n_state; P.m = d->n_ctrl; P.T = d->T;
     P.dyn = dyn_id; P.max_iter = max_iter;
-    hipLaunchKernelGGL(line_search_kernel, dim3((P.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, P);
+    const dim3 grid((P.B + 63) / 64), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    using namespace dqp::dyn;
+    switch (dyn_id) {
+    case 0:
+#define X(a, b) if (P.n == a && P.m == b) { hipLaunchKernelGGL((line_search_kernel<LinStepT<a, b>>), grid, block, 0, st, P); break; }
+        DQP_LIN_SIZES
+#undef X
+        hipLaunchKernelGGL(line_search_kernel<LinStep>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM1L: hipLaunchKernelGGL(line_search_kernel<ModelStep<Robot<Pendulum1l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE1L: hipLaunchKernelGGL(line_search_kernel<ModelStep<Robot<Cartpole1l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE2L: hipLaunchKernelGGL(line_search_kernel<ModelStep<Robot<Cartpole2l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_EULER: hipLaunchKernelGGL(line_search_kernel<ModelStep<PendulumEuler>>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_DX: hipLaunchKernelGGL(line_search_kernel<ModelStep<PendulumDx>>, grid, block, 0, st, P); break;
+    case DQP_DYN_REXQUADROTOR: hipLaunchKernelGGL(line_search_kernel<ModelStep<RexQuadrotor>>, grid, block, 0, st, P); break;
+    default: return DQP_ERR_BAD_ARG;
+    }
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
@@ -424,7 +437,23 @@ dqp_mpc_rollout_backward(const dqp_mpc_dims *d, int dyn_id, double dt, const dou
     RbP P = {};
     P.F = F; P.x = x; P.u = u; P.g = g_x; P.dx0 = d_x0; P.du = d_u; P.dF = d_F; P.df = d_f;
     P.dt = dt; P.B = d->nbatch; P.n = d->n_state; P.m = d->n_ctrl; P.T = d->T; P.dyn = dyn_id;
-    hipLaunchKernelGGL(rollout_backward_kernel, dim3((P.B + 63) / 64), dim3(64), 0, (hipStream_t)stream, P);
+    const dim3 grid((P.B + 63) / 64), block(64);
+    hipStream_t st = (hipStream_t)stream;
+    using namespace dqp::dyn;
+    switch (dyn_id) {
+    case 0:
+#define X(a, b) if (P.n == a && P.m == b) { hipLaunchKernelGGL((rollout_backward_kernel<LinStepT<a, b>>), grid, block, 0, st, P); break; }
+        DQP_LIN_SIZES
+#undef X
+        hipLaunchKernelGGL(rollout_backward_kernel<LinStep>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM1L: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<Robot<Pendulum1l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE1L: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<Robot<Cartpole1l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE2L: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<Robot<Cartpole2l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_EULER: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<PendulumEuler>>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_DX: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<PendulumDx>>, grid, block, 0, st, P); break;
+    case DQP_DYN_REXQUADROTOR: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<RexQuadrotor>>, grid, block, 0, st, P); break;
+    default: return DQP_ERR_BAD_ARG;
+    }
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
