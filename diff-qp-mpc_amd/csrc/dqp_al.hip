@@ -713,9 +713,11 @@ struct OutP {
 // Between two AL iterations (qpth/AL_mpc.py:296-307): res = constraint residual at the new iterate,
 // lam <- lam + rho res with the inequality block clamped at 0, cost of the iterate and the norm of
 // the clamped residual; 16 lanes per problem, dynamics evaluated in the kernel.
+template <class Map>
 __global__ __launch_bounds__(256) void al_outer_kernel(OutP P)
 {
-    const int n = P.n, m = P.m, T = P.T, nt = n + m, neq = T * n, ncon = neq + 2 * T * m;
+    constexpr int n = Map::NX, m = Map::NU, nt = n + m;
+    const int T = P.T, neq = T * n, ncon = neq + 2 * T * m;
     const long long item = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int r = threadIdx.x & 15;
     const long long b = item < P.B ? item : P.B - 1;
@@ -726,18 +728,12 @@ __global__ __launch_bounds__(256) void al_outer_kernel(OutP P)
     const double rho = P.rho[b];
     double cost = 0.0, rn2 = 0.0;
     for (int t = r; t < T; t += 16) {
-        double z[16], xn[12];
+        double z[nt], xn[n];
+#pragma unroll
         for (int j = 0; j < nt; ++j) z[j] = xu[t * nt + j];
         for (int j = 0; j < nt; ++j) cost += (0.5 * Qd[t * nt + j] * z[j] + q[t * nt + j]) * z[j];
         if (t < T - 1) {
-            switch (P.dyn) {
-            case DQP_DYN_PENDULUM1L: step_knot<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>(z, z + n, P.dt, xn); break;
-            case DQP_DYN_CARTPOLE1L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>(z, z + n, P.dt, xn); break;
-            case DQP_DYN_CARTPOLE2L: step_knot<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>(z, z + n, P.dt, xn); break;
-            case DQP_DYN_PENDULUM_EULER: step_knot<dqp::dyn::PendulumEuler>(z, z + n, P.dt, xn); break;
-            case DQP_DYN_REXQUADROTOR: step_knot<dqp::dyn::RexQuadrotor>(z, z + n, P.dt, xn); break;
-            default: step_knot<dqp::dyn::PendulumDx>(z, z + n, P.dt, xn); break;
-            }
+            Map::template step<double>(z, z + n, P.dt, xn);
             for (int j = 0; j < n; ++j) {
                 const double res = xu[(t + 1) * nt + j] - xn[j];
                 rn2 += res * res;
@@ -763,6 +759,21 @@ __global__ __launch_bounds__(256) void al_outer_kernel(OutP P)
     cost = dqp::r16::row_sum(cost);
     rn2 = dqp::r16::row_sum(rn2);
     if (live && r == 0) { P.cost[b] = cost; P.resn[b] = sqrt(rn2); }
+}
+
+int launch_outer(const OutP &P, hipStream_t st)
+{
+    const dim3 grid((unsigned)((P.B + 15) / 16)), block(256);
+    switch (P.dyn) {
+    case DQP_DYN_PENDULUM1L: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE1L: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE2L: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_EULER: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::PendulumEuler>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_DX: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::PendulumDx>, grid, block, 0, st, P); break;
+    case DQP_DYN_REXQUADROTOR: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::RexQuadrotor>, grid, block, 0, st, P); break;
+    default: return DQP_ERR_BAD_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
 struct SelP {
@@ -1002,8 +1013,7 @@ dqp_al_outer_update(const dqp_al_mpc_dims *d, int dyn_id, double dt, const doubl
         return DQP_ERR_BAD_ARG;
     OutP P = {xu, x0, lam, rho, Qdiag, q, u_lower, u_upper, lam_new, cost, res_norm, dt, d->nbatch, d->n_state,
               d->n_ctrl, d->T, dyn_id};
-    hipLaunchKernelGGL(al_outer_kernel, dim3((unsigned)((P.B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, P);
-    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+    return launch_outer(P, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -48,6 +48,10 @@ __global__ __launch_bounds__(256) void jac_kernel(int N, const double *x, const 
         for (int k = 0; k < NU; ++k) uv[k] = u[i * NU + k];
 #pragma unroll
         for (int c0 = 0; c0 < NS; c0 += KC) {
+            // the passes are independent: without this the scheduler interleaves them and the register
+            // demand is that of all passes together (the 12-state model: 3 KB of scratch per lane)
+#pragma unroll
+            for (int k = 0; k < NX; ++k) asm volatile("" : "+v"(xv[k]) : : "memory");
             S xs[NX], us[NU], out[NX];
 #pragma unroll
             for (int k = 0; k < NX; ++k) {
@@ -209,7 +213,7 @@ __attribute__((visibility("default"))) int dqp_dyn_jacobian(int id, int32_t n, c
     case DQP_DYN_CARTPOLE1L: return run_jac<Robot<Cartpole1l>, 5>(n, x, u, dt, x_next, Jx, Ju, stream);
     case DQP_DYN_CARTPOLE2L: return run_jac<Robot<Cartpole2l>, 4>(n, x, u, dt, x_next, Jx, Ju, stream);
     case DQP_DYN_PENDULUM_EULER: return run_jac<PendulumEuler, 3>(n, x, u, dt, x_next, Jx, Ju, stream);
-    case DQP_DYN_REXQUADROTOR: return run_jac<RexQuadrotor, 4>(n, x, u, dt, x_next, Jx, Ju, stream);
+    case DQP_DYN_REXQUADROTOR: return run_jac<RexQuadrotor, 2>(n, x, u, dt, x_next, Jx, Ju, stream);
     default: return run_jac<PendulumDx, 4>(n, x, u, dt, x_next, Jx, Ju, stream);
     }
 }
