@@ -49,13 +49,14 @@ PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2", "final_pmc_summary.json")
 
 
 def library_fingerprint():
-    """sha1 over the kernel sources: a PMC summary is only quoted for the library it was taken on."""
+    """sha1 over the sources of the kernels this command runs (dense QP forward / backward, batch-rule
+    reduction): a PMC summary is only quoted for the kernels it was taken on."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(ROOT, "diff-qp-mpc_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")):
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("dqp_common.h", "dqp_r16_prims.h", "dqp_r16n.hip", "dqp_r16.hip", "dqp_term.hip", "dqp_pdipm.hip",
+              "dqp_dispatch.hip"):
+        h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 
 
