@@ -683,8 +683,102 @@ __global__ __launch_bounds__(256) void al_ls_kernel(LsAP P)
     if (r == 0 && item < total) P.merit[item] = acc;
 }
 
+// The same merits with one lane GROUP per problem that walks its candidates itself (T <= 32): the
+// problem's xu, upd, Qd, q and multipliers are loaded once into registers instead of once per
+// candidate, and the group is as wide as the horizon needs (TPI = 8, 16 or 32 lanes: one knot per lane in
+// the model phase -- with 16 lanes per candidate a T = 5 problem used 5 of them).
+template <int TPI> __device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+    for (int off = TPI / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <class Map, int TPI>
+__global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
+{
+    constexpr int n = Map::NX, m = Map::NU, nt = n + m, ZS = nt | 1;
+    extern __shared__ double lsg_lds[];
+    const int T = P.T, neq = T * n, ncon = neq + 2 * T * m, nzq = T * nt;
+    const int nc = P.ncand > 0 ? P.ncand : 1;
+    const int grp = threadIdx.x / TPI, r = threadIdx.x % TPI;
+    const long long pb = (long long)blockIdx.x * (256 / TPI) + grp;
+    const bool live = pb < P.B;
+    const long long b = live ? pb : P.B - 1;
+    const double *xu = P.xu + b * (long long)nzq, *up = P.upd + b * (long long)nzq;
+    const double *Qd = P.Qd + b * (long long)nzq, *q = P.q + b * (long long)nzq;
+    const double *lam = P.lam + b * (long long)ncon, *x0 = P.x0 + b * (long long)n;
+    const double rho = P.rho[b];
+    double *zb = lsg_lds + (size_t)grp * T * ZS;
+    // ---- the problem, once: element e = r + TPI i of the (T, nt) arrays
+    double ex[nt], eu[nt], eq[nt], el[nt], lu[nt], ll[nt], hi[nt], lo[nt];
+#pragma unroll
+    for (int i = 0; i < nt; ++i) {
+        const int e = r + TPI * i, ec = e < nzq ? e : 0, t = ec / nt, j = ec - t * nt;
+        const bool ok = e < nzq;
+        ex[i] = ok ? xu[ec] : 0.0; eu[i] = (ok && P.ncand > 0) ? up[ec] : 0.0;
+        eq[i] = ok ? Qd[ec] : 0.0; el[i] = ok ? q[ec] : 0.0;
+        const bool isu = ok && j >= n;
+        const int iu = isu ? j - n : 0, row = neq + t * 2 * m + iu;
+        lu[i] = isu ? lam[row] : 0.0; ll[i] = isu ? lam[row + m] : 0.0;
+        hi[i] = isu ? P.uu[iu] : INFINITY; lo[i] = isu ? P.ul[iu] : -INFINITY;
+        if (ok && t == 0 && j < n) { ex[i] = x0[j]; eu[i] = 0.0; }            // x_0 pinned to x0 (al_utils.py:515)
+    }
+    double ly[n];
+#pragma unroll
+    for (int j = 0; j < n; ++j) ly[j] = (r < T - 1) ? lam[r * n + j] : 0.0;
+    // candidates k = blockIdx.y, blockIdx.y + gridDim.y, ...: small batches are split over more wavefronts
+    for (int k = blockIdx.y; k < nc; k += gridDim.y) {
+        const double step = P.ncand > 0 ? (double)exp2f(-(float)k) : 0.0;    // float steps, as the reference
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < nt; ++i) {
+            const int e = r + TPI * i;
+            if (e < nzq) {
+                const int t = e / nt, j = e - t * nt;
+                const double z = fma(step, eu[i], ex[i]);
+                zb[t * ZS + j] = z;
+                acc += (0.5 * eq[i] * z + el[i]) * z;
+                const double vh = z - hi[i], vl = lo[i] - z;
+                if (j >= n)
+                    acc += lu[i] * vh + ll[i] * vl + 0.5 * rho * (fmax(vh, 0.0) * fmax(vh, 0.0) + fmax(vl, 0.0) * fmax(vl, 0.0));
+            }
+        }
+        __syncthreads();
+        if (r < T - 1) {
+            double z[nt], xn[n];
+#pragma unroll
+            for (int j = 0; j < nt; ++j) z[j] = zb[r * ZS + j];
+            Map::template step<double>(z, z + n, P.dt, xn);
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                const double res = zb[(r + 1) * ZS + j] - xn[j];
+                acc += (0.5 * rho * res + ly[j]) * res;
+            }
+        }
+        __syncthreads();
+        acc = group_sum<TPI>(acc);
+        if (r == 0 && live) P.merit[(long long)k * P.B + b] = acc;
+    }
+}
+
+template <class Map, int TPI> int launch_ls_group(const LsAP &P, hipStream_t st)
+{
+    constexpr int ZS = (Map::NX + Map::NU) | 1, G = 256 / TPI;
+    const size_t lds = (size_t)G * P.T * ZS * sizeof(double);
+    const unsigned blocks = (unsigned)((P.B + G - 1) / G);
+    // at least ~2 wavefronts per SIMD where the batch alone does not give them: split the candidates
+    unsigned split = 1;
+    if (P.ncand > 1) while (split < 4 && (unsigned long long)blocks * 4 * split < 2048) split *= 2;
+    hipLaunchKernelGGL((al_ls_group_kernel<Map, TPI>), dim3(blocks, split), dim3(256), lds, st, P);
+    return DQP_OK;
+}
+
 template <class Map> int launch_ls_t(const LsAP &P, hipStream_t st)
 {
+    if (P.T <= 8) return launch_ls_group<Map, 8>(P, st);
+    if (P.T <= 16) return launch_ls_group<Map, 16>(P, st);
+    if (P.T <= 32) return launch_ls_group<Map, 32>(P, st);
     const long long items = (long long)(P.ncand > 0 ? P.ncand : 1) * P.B;
     hipLaunchKernelGGL(al_ls_kernel<Map>, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, P);
     return DQP_OK;
