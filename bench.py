@@ -210,8 +210,8 @@ def timed_steps(hp, steps, world, gathered):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)       # 200 x 0.31 ms: a 60 ms timed region
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--termination", choices=["batch", "per_problem"], default="batch",
                     help="mode of the headline number (default: the parity-safe batch rule)")
