@@ -64,7 +64,7 @@ class dqp_al_dims(ctypes.Structure):
 
 class dqp_mpc_dims(ctypes.Structure):
     _fields_ = [("nbatch", ctypes.c_int32), ("n_state", ctypes.c_int32), ("n_ctrl", ctypes.c_int32),
-                ("T", ctypes.c_int32), ("has_bounds", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("T", ctypes.c_int32), ("has_bounds", ctypes.c_int32), ("dyn_id", ctypes.c_int32)]
 
 _lib = None
 

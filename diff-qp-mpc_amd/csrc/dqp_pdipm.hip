@@ -848,16 +848,22 @@ static int mpc_params(const dqp_mpc_dims *md, const dqp_opts *opts, KParams &P, 
     d.nz = md->T * (md->n_state + md->n_ctrl);
     d.nineq = 2 * md->T * md->n_ctrl;
     d.neq = md->T * md->n_state;
-    if (r16n_workspace_doubles(d.nz, d.nineq, d.neq) > 0) {
-        int rc = fill_params(&d, opts, P, lds);
+    if (md->dyn_id) {       // true-dynamics residual: a registered model of this size, stage-wise kernels
+        int32_t dn = 0, dm = 0;
+        if (dqp_dyn_sizes(md->dyn_id, &dn, &dm) != DQP_OK || dn != md->n_state || dm != md->n_ctrl) return DQP_ERR_BAD_ARG;
+    }
+    if (!md->dyn_id && r16n_workspace_doubles(d.nz, d.nineq, d.neq) > 0) {
+        dqp_opts o2;
+        if (opts) { o2 = *opts; o2.dyn_id = 0; }
+        int rc = fill_params(&d, opts ? &o2 : nullptr, P, lds);
         if (rc != DQP_OK) return rc;
-        if (P.dynId) return DQP_ERR_BAD_ARG;
         kind = MPC_R16N;
     } else if (ric_supported(md->n_state, md->n_ctrl)) {
-        if (opts && opts->dyn_id) return DQP_ERR_BAD_ARG;
         P.stamps = nullptr;
         P.B = d.nbatch; P.N = d.nz; P.M = d.nineq; P.E = d.neq;
         fill_opts(opts, P);
+        P.dynId = md->dyn_id;
+        P.dynDt = opts ? opts->dyn_dt : 0.0;
         kind = MPC_RIC;
     } else {
         return DQP_ERR_TOO_LARGE;
@@ -918,6 +924,7 @@ dqp_mpc_qp_forward(const dqp_mpc_dims *md, const dqp_opts *opts, const double *C
     if (P.B == 0) return DQP_OK;
     if (!C || !c || !F || !f || !x0 || !u_lower || !u_upper || !tau || !lam || !nu || !slack || !workspace)
         return DQP_ERR_BAD_ARG;
+    if (P.dynId && !(P.dynDt > 0.0)) return DQP_ERR_BAD_ARG;        // the model's step needs dqp_opts.dyn_dt
     auto run = [&](const KParams &Q) { return kind == MPC_R16N ? r16n_forward(Q, stream) : ric_forward(Q, stream); };
     P.mC = C; P.mc = c; P.mF = F; P.mf = f; P.mx0 = x0; P.mul = u_lower; P.muu = u_upper;
     P.zhat = tau; P.lam = lam; P.nu = nu; P.slack = slack; P.info = info; P.best_resid = best_resid;

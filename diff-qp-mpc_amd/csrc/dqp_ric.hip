@@ -33,6 +33,7 @@
 #include "../../include/dqp.h"
 #include "dqp_common.h"
 #include "dqp_r16_prims.h"
+#include "dqp_dyn_models.h"
 
 namespace dqp {
 namespace ric {
@@ -175,6 +176,39 @@ __device__ __forceinline__ bool factor(const Ctx<C> &K, bool unit, bool clampd)
     return ok;
 }
 
+// f(x_t, u_t)[r] of a registered model for the knot distributed as `tau`: every lane gathers the knot,
+// evaluates the step (redundantly: the models are a few hundred FLOP) and keeps its own component.
+template <class C, class Map>
+__device__ __forceinline__ double model_component(double tau, double dt, int r)
+{
+    if constexpr (Map::NX == C::NX && Map::NU == C::NU) {
+        double z[C::NT], xn[C::NX];
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) z[j] = rb(tau, j);
+        Map::template step<double>(z, z + C::NX, dt, xn);
+        double v = 0.0;
+#pragma unroll
+        for (int j = 0; j < C::NX; ++j) v = (r == j) ? xn[j] : v;
+        return v;
+    } else {
+        return 0.0;
+    }
+}
+template <class C>
+__device__ __forceinline__ double model_next(int dyn_id, double tau, double dt, int r)
+{
+    using namespace dqp::dyn;
+    switch (dyn_id) {
+    case DQP_DYN_PENDULUM1L: return model_component<C, Robot<Pendulum1l>>(tau, dt, r);
+    case DQP_DYN_CARTPOLE1L: return model_component<C, Robot<Cartpole1l>>(tau, dt, r);
+    case DQP_DYN_CARTPOLE2L: return model_component<C, Robot<Cartpole2l>>(tau, dt, r);
+    case DQP_DYN_PENDULUM_EULER: return model_component<C, PendulumEuler>(tau, dt, r);
+    case DQP_DYN_PENDULUM_DX: return model_component<C, PendulumDx>(tau, dt, r);
+    case DQP_DYN_REXQUADROTOR: return model_component<C, RexQuadrotor>(tau, dt, r);
+    default: return 0.0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // One backward sweep for the three things an iteration needs from every knot before it can move:
 // the residuals of the iterate (batch.py:93-108: rx = C tau + c + G'z + A'y, rz = G tau + s - h,
@@ -231,9 +265,12 @@ __device__ __forceinline__ bool factor_fused(const Ctx<C> &K, double &nx2, doubl
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc = fma(fcol[i], rb(yt, i), acc);
             rx += acc;
-            const double fx = mv_row<NT>(frow, tau);
+            // ry_t: the linearised dynamics, or the registered model itself (the reference's dyn_res closure,
+            // qp_wrapper.py:309,316 -> batch_LU.py:97)
+            const double fx = K.P.dynId ? model_next<C>(K.P.dynId, tau, K.P.dynDt, r)
+                                        : mv_row<NT>(frow, tau) + (K.xl ? K.P.mf[((long long)t * K.P.B + K.qp) * NX + r] : 0.0);
             if (K.xl) {
-                e = fx - w[L.X + (t + 1) * NT + r] + K.P.mf[((long long)t * K.P.B + K.qp) * NX + r];
+                e = fx - w[L.X + (t + 1) * NT + r];
                 w[L.RY + t * NX + r] = e;
                 ny2 = fma(e, e, ny2);
             }

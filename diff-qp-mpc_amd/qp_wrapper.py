@@ -138,12 +138,12 @@ class _MPCQP(Function):
     the backward straight into (dC, dc, dF, df, dx0) (dqp_mpc_qp_backward)."""
 
     @staticmethod
-    def supported(B, n_state, n_ctrl, T):
-        dims = _lib.dqp_mpc_dims(B, n_state, n_ctrl, T, 1, 0)
+    def supported(B, n_state, n_ctrl, T, dyn=None):
+        dims = _lib.dqp_mpc_dims(B, n_state, n_ctrl, T, 1, dyn.id if dyn is not None else 0)
         return bool(_lib.load().dqp_mpc_qp_supported(ctypes.byref(dims)))
 
     @staticmethod
-    def forward(ctx, C, c, F, f, x0, u_lower, u_upper, n_state, n_ctrl, T):
+    def forward(ctx, C, c, F, f, x0, u_lower, u_upper, n_state, n_ctrl, T, dyn=None):
         from . import qp as qpmod
         lib = _lib.load()
         for t in (C, c, F, f, x0):
@@ -155,9 +155,13 @@ class _MPCQP(Function):
         keep = [cv(C), cv(c), cv(F), cv(f), cv(x0), cv(u_lower).reshape(-1), cv(u_upper).reshape(-1)]
         if keep[5].numel() != n_ctrl or keep[6].numel() != n_ctrl:
             raise RuntimeError("u_lower/u_upper must have shape (n_ctrl,) (qp_wrapper.py:677-678)")
-        dims = _lib.dqp_mpc_dims(B, n_state, n_ctrl, T, 1, 0)
+        # dyn: a DeviceDynamics whose true step is the equality residual of the iterations (the reference's
+        # dyn_res closure, qp_wrapper.py:309,316); F, f stay the linearisation the Newton steps use
+        dims = _lib.dqp_mpc_dims(B, n_state, n_ctrl, T, 1, dyn.id if dyn is not None else 0)
         batch = qpmod.TERMINATION == "batch"
         opts = _lib.dqp_opts(1e-12, qpmod.STALL_TOL, 20, 3, _lib.DQP_FLAG_BATCH_TERMINATION if batch else 0, 0)
+        if dyn is not None:
+            opts.dyn_dt = dyn.dt
         kw = dict(dtype=torch.float64, device=dev)
         tau = torch.empty(B, T, nt, **kw)
         lam = torch.empty(B, 2 * T * n_ctrl, **kw); slack = torch.empty(B, 2 * T * n_ctrl, **kw)
@@ -195,7 +199,7 @@ class _MPCQP(Function):
                                          ctypes.c_void_p(0), _ptr(ctx.ws), _stream(dev))
         _lib.check(rc, "dqp_mpc_qp_backward")
         outs = [None if o is None else o.to(ctx.dtype) for o in outs]
-        return (*outs, None, None, None, None, None)
+        return (*outs, None, None, None, None, None, None)
 
 
 class _Rollout(Function):
@@ -361,10 +365,13 @@ class MPC(Module):
             as_t = lambda v: (torch.full((self.n_ctrl,), float(v), dtype=torch.float64, device=x0.device)
                               if isinstance(v, float) else v.to(x0.device))
             ul, uu = as_t(self.u_lower), as_t(self.u_upper)
-        if (FUSED_MPC_QP and dyn_res is None and not self.add_goal_constraint and ul is not None
-                and _MPCQP.supported(self.n_batch, self.n_state, self.n_ctrl, self.T)):
-            # assembly + QP + (in backward) the assembly's adjoint in one kernel each way
-            tau = _MPCQP.apply(cost.C, cost.c, F, f, x0, ul, uu, self.n_state, self.n_ctrl, self.T)
+        dyn_model = dyn_res.dynamics if isinstance(dyn_res, DynamicsResidual) else None
+        if (FUSED_MPC_QP and (dyn_res is None or dyn_model is not None) and not self.add_goal_constraint
+                and ul is not None
+                and _MPCQP.supported(self.n_batch, self.n_state, self.n_ctrl, self.T, dyn_model)):
+            # assembly + QP + (in backward) the assembly's adjoint in one kernel each way; with a registered
+            # model the stage-wise kernels evaluate the true-dynamics residual themselves
+            tau = _MPCQP.apply(cost.C, cost.c, F, f, x0, ul, uu, self.n_state, self.n_ctrl, self.T, dyn_model)
             x_qp, u_qp = tau[..., :self.n_state].transpose(0, 1), tau[..., self.n_state:].transpose(0, 1)
             return x_qp - x, u_qp - u, (self.compute_cost(tau, cost) if need_cost else None)
         Q, q, G, h, A, b = _AssembleDenseQP.apply(cost.C, cost.c, F, f, x0, ul, uu,

@@ -181,7 +181,10 @@ typedef struct dqp_mpc_dims {
     int32_t n_ctrl;
     int32_t T;            /* horizon; nz = T (n_state+n_ctrl), neq = T n_state                */
     int32_t has_bounds;   /* 1: nineq = 2 T n_ctrl (box on u); 0: nineq = n_ctrl placeholder  */
-    int32_t reserved;
+    int32_t dyn_id;       /* dqp_mpc_qp_*: 0, or a registered model (DQP_DYN_*) whose true step replaces
+                             F tau + f in the equality residual of the PDIPM iterations -- the
+                             reference's dyn_res closure (qp_wrapper.py:309,316); step = dqp_opts.dyn_dt.
+                             Served by the stage-wise kernels.  Ignored by dqp_mpc_assemble etc.       */
 } dqp_mpc_dims;
 
 /*

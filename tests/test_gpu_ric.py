@@ -190,3 +190,64 @@ def test_mpc_mirror_vs_reference_n12_m4(name, T, tag, kw):
     for k, t in (("C", C), ("c", c), ("F", F), ("f", f), ("x0", x0)):
         got = t.grad.cpu().numpy() if t.grad is not None else np.zeros(t.shape)
         np.testing.assert_allclose(got, g["%s_d%s" % (tag, k)], err_msg="%s d%s" % (tag, k), **GT)
+
+
+@pytest.mark.parametrize("robot,T", [("cartpole1l", 5), ("pendulum_dx", 10), ("cartpole2l", 4)])
+def test_true_dynamics_residual_stagewise_equals_dense(robot, T):
+    """qp_wrapper.MPC on a registered nonlinear model: the equality residual of the PDIPM iterations is
+    the model's true step (the reference's dyn_res closure, qp_wrapper.py:309,316).  The stage-wise
+    kernels evaluate it per knot; the dense one-QP-per-wavefront kernels do the same through
+    dqp_opts.dyn_* (pinned by the reference's config-2 golden).  Same trajectories and gradients."""
+    from diff_qp_mpc_amd import qp_wrapper
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    dyn = DeviceDynamics(robot)
+    n, m, B = dyn.n_state, dyn.n_ctrl, 12
+    gen = torch.Generator().manual_seed(T)
+    rnd = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).cuda()
+    x0 = 0.3 * rnd(B, n)
+    if robot == "pendulum_dx":
+        x0[:, :2] = torch.nn.functional.normalize(x0[:, :2] + torch.tensor([1.0, 0.0]).cuda(), dim=1)
+    L = 0.3 * rnd(T, B, n + m, n + m)
+    outs = {}
+    for fused in (True, False):
+        qp_wrapper.FUSED_MPC_QP = fused
+        try:
+            C = (L @ L.transpose(2, 3) + torch.eye(n + m, dtype=torch.float64, device="cuda")).requires_grad_()
+            c = (0.2 * torch.ones(T, B, n + m, dtype=torch.float64, device="cuda")).requires_grad_()
+            mpc = qp_wrapper.MPC(n, m, T, u_lower=-torch.ones(m).double().cuda(), u_upper=torch.ones(m).double().cuda(),
+                                 n_batch=B, verbose=-1, single_qp_solve=True)
+            x, u = mpc(x0, qp_wrapper.QuadCost(C, c), dyn, dyn.jac)
+            (x.sum() + 2.0 * u.sum()).backward()
+            outs[fused] = [t.detach().cpu().numpy() for t in (x, u, C.grad, c.grad)]
+        finally:
+            qp_wrapper.FUSED_MPC_QP = True
+    for a, b, k in zip(outs[True], outs[False], ("x", "u", "dC", "dc")):
+        np.testing.assert_allclose(a, b, rtol=1e-5, atol=1e-7, err_msg=k)
+
+
+def test_quadrotor_interior_point_mpc_runs_at_config4_horizon():
+    """qp_wrapper.MPC (interior point) on the quadrotor device model at T = 30 (nz = 480): linearisation from
+    the registry's Jacobians, stage-wise PDIPM with the true RK4 step as equality residual, fused line
+    search on the model.  B = 64; properties: finite, x_0 = x0, controls inside the bounds (the returned
+    point is the damped QP step x + alpha dx of qp_wrapper.py:298-324, not a rollout), finite gradients."""
+    from diff_qp_mpc_amd import qp_wrapper
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    dyn = DeviceDynamics("rexquadrotor")
+    n, m, T, B = 12, 4, 30, 64
+    rng = np.random.default_rng(0)
+    x0 = dev(rng.uniform(-1, 1, (B, n)) * np.array([1.0] * 3 + [0.15] * 3 + [0.5] * 3 + [0.25] * 3))
+    Qw = torch.tensor([10.0] * 3 + [0.01] * 3 + [1.0] * 3 + [0.01] * 3 + [1e-4] * m, dtype=torch.float64, device="cuda")
+    hover = (2.0 * 9.81 + 4 * 30.48576) / (4 * 0.0244101 * 100.0)
+    C = torch.diag(Qw).repeat(T, B, 1, 1).requires_grad_()
+    ref = torch.cat([torch.zeros(n, dtype=torch.float64, device="cuda"), torch.full((m,), hover, dtype=torch.float64, device="cuda")])
+    c = (-(Qw * ref)).repeat(T, B, 1).requires_grad_()
+    lo, hi = torch.full((m,), 11.5, dtype=torch.float64, device="cuda"), torch.full((m,), 18.3, dtype=torch.float64, device="cuda")
+    mpc = qp_wrapper.MPC(n, m, T, u_lower=lo, u_upper=hi, n_batch=B, verbose=-1, qp_iter=2,
+                         u_init=torch.full((T, B, m), hover, dtype=torch.float64, device="cuda"))
+    x, u = mpc(x0, qp_wrapper.QuadCost(C, c), dyn, dyn.jac)
+    assert x.shape == (T, B, n) and u.shape == (T, B, m)
+    assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(u).all())
+    assert float((x[0] - x0).detach().abs().max()) < 1e-9
+    assert float(u.min()) >= 11.5 - 1e-6 and float(u.max()) <= 18.3 + 1e-6
+    (x.sum() + u.sum()).backward()
+    assert bool(torch.isfinite(C.grad).all()) and bool(torch.isfinite(c.grad).all())
