@@ -167,6 +167,23 @@ class MPC(Module):
         return al_utils.merit_grad_hessian(xu, Q, q, dx, dx_jac, x0, lamda, rho, self.x_lower,
                                            self.x_upper, self.u_lower, self.u_upper, self.diag_cost)
 
+    def merit_hessian(self, xu, Q, q, dx, dx_jac, x0, lamda, rho):
+        """AL_mpc.py:325-326: the dense merit Hessian diag(Q) + rho Jc^T Jc (B, nz, nz)."""
+        _, terms = self.merit_grad_hess(xu, Q, q, dx, dx_jac, x0, lamda, rho)
+        return terms.dense()
+
+    def dyn_res_eq(self, x, u, dx, x0, mask=None):
+        """AL_mpc.py:330-355 (the mask is unused there too)."""
+        return al_utils.dyn_res_eq(x, u, dx, x0)
+
+    def dyn_res_ineq(self, x, u, dx, x0):
+        """AL_mpc.py:357-383: (res, res_clamp) of the control bounds."""
+        return al_utils.dyn_res_ineq(x, u, x0, self.x_lower, self.x_upper, self.u_lower, self.u_upper)
+
+    def rollout_lin(self, x, actions, F, f):
+        """AL_mpc.py:414-424: batch-major rollout under time-varying linear dynamics."""
+        return self.rollout(x, actions, LinDx(F, f))          # this class's rollout indexes LinDx batch-major
+
     def dyn_res(self, xu, dx, x0, res_type='clamp'):
         res, res_clamp = al_utils.dyn_res(xu, dx, x0, self.x_lower, self.x_upper, self.u_lower, self.u_upper)
         if res_type == 'noclamp':

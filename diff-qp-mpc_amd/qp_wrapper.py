@@ -509,7 +509,7 @@ class MPC(Module):
     # ------------------------------------------------------------------ behaviour of qp_wrapper.py:598-611
     def rollout(self, x, actions, dynamics):
         """States (T,B,n) reached from x under `actions` (T,B,m); the last action is unused."""
-        if (FUSED_LINE_SEARCH and x.is_cuda and self.n_state <= 8 and self.n_ctrl <= 8
+        if (FUSED_LINE_SEARCH and x.is_cuda and self.n_state <= 12 and self.n_ctrl <= 8
                 and (isinstance(dynamics, DeviceDynamics) or (isinstance(dynamics, LinDx) and dynamics.f is not None))):
             if isinstance(dynamics, LinDx):
                 return _Rollout.apply(x, actions, dynamics.F, dynamics.f, None, self.n_state, self.n_ctrl, self.T)
@@ -522,6 +522,45 @@ class MPC(Module):
             else:
                 states.append(dynamics(states[-1], actions[t]))
         return torch.stack(states, dim=0)
+
+    def rollout_lin(self, x, actions, F, f):
+        """qp_wrapper.py:614-624: the rollout under time-varying linear dynamics (time-major)."""
+        return self.rollout(x, actions, LinDx(F, f))
+
+    # ---- the dense assembly as the reference exposes it (qp_wrapper.py:638-679); the solver path itself
+    # never materialises these for shapes with a fused MPC QP kernel
+    def _dense(self, C, c, F, f, x0):
+        as_t = lambda v: (torch.full((self.n_ctrl,), float(v), dtype=torch.float64, device=x0.device)
+                          if isinstance(v, float) else v.to(x0.device))
+        ul = as_t(self.u_lower) if self.u_lower is not None else None
+        uu = as_t(self.u_upper) if self.u_upper is not None else None
+        return _AssembleDenseQP.apply(C, c, F, f, x0, ul, uu, self.n_state, self.n_ctrl, self.T)
+
+    def compute_Qq_dense(self, C, c):
+        B = C.shape[1]
+        z = lambda *s: torch.zeros(*s, dtype=C.dtype, device=C.device)
+        nt = self.n_state + self.n_ctrl
+        Q, q = self._dense(C, c, z(self.T - 1, B, self.n_state, nt), z(self.T - 1, B, self.n_state), z(B, self.n_state))[:2]
+        return Q, q
+
+    def compute_Ab_dense(self, F, f, x0):
+        B = x0.shape[0]
+        z = lambda *s: torch.zeros(*s, dtype=F.dtype, device=F.device)
+        nt = self.n_state + self.n_ctrl
+        out = self._dense(z(self.T, B, nt, nt), z(self.T, B, nt), F, f, x0)
+        return out[4], out[5]
+
+    def compute_Gh_dense(self, x0):
+        B = x0.shape[0]
+        z = lambda *s: torch.zeros(*s, dtype=x0.dtype, device=x0.device)
+        nt = self.n_state + self.n_ctrl
+        out = self._dense(z(self.T, B, nt, nt), z(self.T, B, nt), z(self.T - 1, B, self.n_state, nt),
+                          z(self.T - 1, B, self.n_state), x0)
+        return out[2], out[3]
+
+    def approximate_cost(self, x, u, Cf, diff=True):
+        raise NotImplementedError("approximate_cost (qp_wrapper.py:438-489) is never called in the reference: "
+                                  "its MPC.forward takes QuadCost only")
 
     # ------------------------------------------------------------------ behaviour of qp_wrapper.py:326-345
     def dyn_res(self, x, dx, x0):

@@ -379,3 +379,26 @@ def test_fused_rollout_and_its_adjoint(kind):
     np.testing.assert_allclose(res[True][0].cpu().numpy(), res[False][0].cpu().numpy(), rtol=1e-12, atol=1e-12)
     for a, b in zip(res[True][1:], res[False][1:]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-10)
+
+
+def test_reference_helper_methods_exist_and_agree():
+    """The helper methods a reference caller may reach for (qp_wrapper.py:614-679: rollout_lin,
+    compute_Qq_dense / compute_Ab_dense / compute_Gh_dense) against the golden's dense QP, which the
+    reference's own compute_*_dense produced (make_golden.py)."""
+    from diff_qp_mpc_amd import qp_wrapper
+    g = load("M_metric_b8")
+    n, m, T = 3, 3, 5
+    B = g["mpc_x0"].shape[0]
+    C, c, F, f, x0 = [dev(g["mpc_" + k]) for k in ("C", "c", "F", "f", "x0")]
+    mpc = qp_wrapper.MPC(n, m, T, u_lower=dev(g["mpc_u_lower"]), u_upper=dev(g["mpc_u_upper"]), n_batch=B, verbose=-1)
+    Q, q = mpc.compute_Qq_dense(C, c)
+    A, b = mpc.compute_Ab_dense(F, f, x0)
+    G, h = mpc.compute_Gh_dense(x0)
+    for got, key in ((Q, "Q"), (q, "p"), (A, "A"), (b, "b"), (G, "G"), (h, "h")):
+        np.testing.assert_array_equal(got.cpu().numpy(), g["in_" + key])
+    u = torch.zeros(T, B, m, dtype=torch.float64, device="cuda")
+    xs = mpc.rollout_lin(x0, u, F, f)
+    ref = [x0]
+    for t in range(T - 1):
+        ref.append((F[t] @ torch.cat([ref[-1], u[t]], -1).unsqueeze(-1)).squeeze(-1) + f[t])
+    np.testing.assert_allclose(xs.cpu().numpy(), torch.stack(ref).cpu().numpy(), rtol=0, atol=1e-14)
