@@ -126,6 +126,49 @@ def constraint_jacobian(xu, x0, dx_jac, u_lower, u_upper):
     return torch.cat((eq, iq), 1), torch.cat((eq, iqc), 1), J, Jc
 
 
+# ---- the reference's own entry points into the Jacobian fill (al_utils.py:105-186,212-318), for callers
+# that use them directly; the solver path goes through assemble_jacobian / the fused kernels
+def constraint_res_jac2(xu, x0, dx_jac, x_lower, x_upper, u_lower, u_upper):
+    """-> (res, res_clamp, constraint_jac, constraint_jac_clamp, constraint_hess) as al_utils.py:162-185."""
+    res, resc, J, Jc = constraint_jacobian(xu, x0, dx_jac, u_lower, u_upper)
+    return res, resc, J, Jc, torch.bmm(Jc.transpose(1, 2), Jc)
+
+
+constraint_res_jac1 = constraint_res_jac2        # al_utils.py:140-160: the same quantities, older fill
+
+
+def dyn_res_eq_jac(x, u, dx_jac, x0):
+    """-> (res_eq (B, T n), its Jacobian (B, T n, T (n+m)))   (al_utils.py:212-262)."""
+    n = x0.shape[-1]
+    m = u.shape[-1]
+    lo = torch.full((m,), -float("inf"), dtype=x.dtype, device=x.device)
+    res, _, J, _ = constraint_jacobian(torch.cat((x, u), 2), x0, dx_jac, lo, -lo)
+    neq = x.shape[1] * n
+    return res[:, :neq], J[:, :neq]
+
+
+def dyn_res_ineq_jac(x, u, x0, x_lower, x_upper, u_lower, u_upper):
+    """-> (res, res_clamp, jac, jac_clamp) of the control-bound rows (al_utils.py:294-318)."""
+    B, T, n = x.shape
+    m = u.shape[-1]
+    res, resc = dyn_res_ineq(x, u, x0, x_lower, x_upper, u_lower, u_upper)
+    J = x.new_zeros(B, T, 2, m, T, n + m)
+    at = torch.arange(T, device=x.device)
+    eye_m = torch.eye(m, dtype=x.dtype, device=x.device)
+    J[:, at, 0, :, at, n:] = eye_m
+    J[:, at, 1, :, at, n:] = -eye_m
+    J = J.reshape(B, 2 * T * m, T * (n + m))
+    return res, resc, J, J * (resc > 0).to(x.dtype)[..., None]
+
+
+def merit_hessian(xu, Q, q, dx_jac, x0, lamda, rho, x_lower, x_upper, u_lower, u_upper, diag_cost=True):
+    """diag(Q) + rho Jc^T Jc, dense (B, nz, nz)   (al_utils.py:105-119)."""
+    B = xu.shape[0]
+    _, _, _, Jc = constraint_jacobian(xu, x0, dx_jac, u_lower, u_upper)
+    Qfull = torch.diag_embed(Q.reshape(B, -1)) if diag_cost else Q
+    return Qfull + rho.reshape(B, 1, 1) * torch.bmm(Jc.transpose(1, 2), Jc)
+
+
 def compute_cost(xu, Q, q, diag_cost=True):
     """al_utils.py:339-351 (diagonal cost)."""
     assert diag_cost

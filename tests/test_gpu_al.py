@@ -409,3 +409,39 @@ def test_banded_newton_step_vs_dense_oracle(robot, T):
     torch.cuda.synchronize()
     np.testing.assert_allclose(out.cpu().numpy().reshape(B, -1),
                                al_oracle.chol_solve_neg(L_ref, rhs.cpu().numpy().reshape(B, -1)), rtol=1e-8, atol=1e-10)
+
+
+def test_reference_entry_points_of_the_jacobian_fill():
+    """al_utils.constraint_res_jac2 / dyn_res_eq_jac / dyn_res_ineq_jac / merit_hessian under the
+    reference's names and return conventions (al_utils.py:105-186,212-318), against the numpy oracle."""
+    from diff_qp_mpc_amd import al_utils
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    dyn = DeviceDynamics("cartpole1l")
+    B, T, n, m = 5, 6, 4, 1
+    gen = torch.Generator().manual_seed(1)
+    xu = 0.5 * torch.randn(B, T, n + m, generator=gen, dtype=torch.float64).cuda()
+    x0 = xu[:, 0, :n] + 0.1
+    lo, hi = dev([-0.3]), dev([0.3])
+    res, resc, J, Jc, H = al_utils.constraint_res_jac2(xu, x0, dyn.jac, None, None, lo, hi)
+
+    def step_np(x, u):
+        xn, (Jx, Ju) = dyn.jac(dev(x), dev(u))
+        return xn.cpu().numpy(), Jx.cpu().numpy(), Ju.cpu().numpy()
+    r0, rc0, J0, Jc0 = al_oracle.constraint_jacobian(xu.cpu().numpy(), x0.cpu().numpy(), lo.cpu().numpy(), hi.cpu().numpy(), step=step_np)
+    np.testing.assert_allclose(res.cpu().numpy(), r0, atol=1e-13)
+    np.testing.assert_allclose(resc.cpu().numpy(), rc0, atol=1e-13)
+    np.testing.assert_allclose(J.cpu().numpy(), J0, atol=1e-12)
+    np.testing.assert_allclose(Jc.cpu().numpy(), Jc0, atol=1e-12)
+    np.testing.assert_allclose(H.cpu().numpy(), Jc0.transpose(0, 2, 1) @ Jc0, atol=1e-11)
+    x, u = xu[..., :n], xu[..., n:]
+    re, Je = al_utils.dyn_res_eq_jac(x, u, dyn.jac, x0)
+    np.testing.assert_allclose(re.cpu().numpy(), r0[:, :T * n], atol=1e-13)
+    np.testing.assert_allclose(Je.cpu().numpy(), J0[:, :T * n], atol=1e-12)
+    ri, ric, Ji, Jic = al_utils.dyn_res_ineq_jac(x, u, x0, None, None, lo, hi)
+    np.testing.assert_allclose(Ji.cpu().numpy(), J0[:, T * n:], atol=0)
+    np.testing.assert_allclose(Jic.cpu().numpy(), Jc0[:, T * n:], atol=0)
+    Qd = torch.rand(B, T, n + m, generator=gen, dtype=torch.float64).cuda() + 0.1
+    rho = dev([[1.0], [10.0], [100.0], [1.0], [10.0]])
+    Hm = al_utils.merit_hessian(xu, Qd, None, dyn.jac, x0, None, rho, None, None, lo, hi)
+    want = np.stack([np.diag(Qd[b].reshape(-1).cpu().numpy()) + float(rho[b]) * Jc0[b].T @ Jc0[b] for b in range(B)])
+    np.testing.assert_allclose(Hm.cpu().numpy(), want, atol=1e-10)
