@@ -145,3 +145,31 @@ def test_fp32_inputs_round_trip(fam):
     for k, t in zip("QpGhAb", ins32):
         assert t.grad.dtype == torch.float32
         np.testing.assert_allclose(t.grad.cpu().numpy()[gm], og["d" + k][gm], rtol=1e-3, atol=1e-4, err_msg="d" + k)
+
+
+def test_sl1qp_reformulation():
+    """sl1qp.sl1qpify (the formulation of sl1qp_mpc.py:703-752 at general sizes, neq != nineq): the
+    extended QP solved on the GPU equals the CPU oracle on the same extended QP; for mu above the
+    multipliers the exact penalty returns the original QP's solution; for a small mu on an
+    over-constrained problem the constraints are softened (violations allowed, finite solution)."""
+    import diff_qp_mpc_amd as dqp
+    from diff_qp_mpc_amd import sl1qp
+    B, nz, nineq, neq = 7, 10, 8, 4
+    Q, p, G, h, A, b = [dev(a).requires_grad_() for a in family(0, B, nz, nineq, neq)]
+    z_hard = dqp.DenseQPFunction(verbose=-1)(Q, p, G, h, A, b)
+    ext = sl1qp.sl1qpify(Q, p, G, h, A, b, mu=200.0)
+    assert ext[0].shape == (B, nz + 2 * neq + nineq, nz + 2 * neq + nineq)
+    assert ext[2].shape == (B, 2 * nineq + 2 * neq, nz + 2 * neq + nineq) and ext[4].shape == (B, neq, nz + 2 * neq + nineq)
+    z_soft = sl1qp.SL1QPFunction(mu=200.0, verbose=-1)(Q, p, G, h, A, b)
+    o = oracle.dense_forward(*[t.detach().cpu().numpy() for t in ext])
+    np.testing.assert_allclose(z_soft.detach().cpu().numpy(), o["zhat"][:, :nz], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(z_soft.detach().cpu().numpy(), z_hard.detach().cpu().numpy(), rtol=1e-3, atol=1e-4)
+    z_soft.sum().backward()
+    assert all(t.grad is not None and bool(torch.isfinite(t.grad).all()) for t in (Q, p, G, h, A, b))
+    # infeasible hard problem (two contradictory equality rows): the l1 form still has a solution
+    A2 = torch.cat([A.detach(), A.detach()[:, :1]], 1)
+    b2 = torch.cat([b.detach(), b.detach()[:, :1] + 1.0], 1)
+    z = sl1qp.SL1QPFunction(mu=5.0, verbose=-1)(Q.detach(), p.detach(), G.detach(), h.detach(), A2, b2)
+    assert bool(torch.isfinite(z).all())
+    gap = (A2 @ z.unsqueeze(-1)).squeeze(-1) - b2
+    assert float(gap[:, [0, neq]].abs().sum(1).min()) > 0.5          # the contradiction is absorbed by the slacks
