@@ -20,8 +20,10 @@ world = int(os.environ.get("WORLD_SIZE", "1"))
 rank = int(os.environ.get("RANK", "0"))
 local = int(os.environ.get("LOCAL_RANK", "0"))
 if world > 1:
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl")
+    # DQP_BENCH_ONE_DEVICE=1 DQP_BENCH_BACKEND=gloo: rehearse the N > 1 code path with all ranks on GPU 0
+    one = os.environ.get("DQP_BENCH_ONE_DEVICE") == "1"
+    torch.cuda.set_device(0 if one else local)
+    dist.init_process_group(os.environ.get("DQP_BENCH_BACKEND", "nccl"))
 robot = os.environ.get("ROBOT", "cartpole2l")
 B, T, deq_iter = int(os.environ.get("BATCH", 8192)), int(os.environ.get("T", 5)), int(os.environ.get("DEQ_ITER", 6))
 dyn = DeviceDynamics(robot, dt=0.03 if robot == "cartpole2l" else 0.05)
