@@ -251,3 +251,36 @@ def test_quadrotor_interior_point_mpc_runs_at_config4_horizon():
     assert float(u.min()) >= 11.5 - 1e-6 and float(u.max()) <= 18.3 + 1e-6
     (x.sum() + u.sum()).backward()
     assert bool(torch.isfinite(C.grad).all()) and bool(torch.isfinite(c.grad).all())
+
+
+@pytest.mark.parametrize("n,m,T,B", [(3, 3, 2, 1), (2, 1, 2, 3), (4, 2, 3, 130)])
+def test_stagewise_edge_sizes(n, m, T, B):
+    """Shortest horizons (T = 2: one dynamics row block), a single problem, a batch that is not a multiple
+    of the four problems a wavefront holds: against the CPU oracle on the assembled QP."""
+    data = problem(n, m, T, B, seed=11 * n + T + B)
+    tau, grads, w = run_fused(n, m, T, data)
+    Q, p, G, h, A, b = assemble(*data)
+    o = oracle.dense_forward(Q, p, G, h, A, b)
+    np.testing.assert_allclose(tau.reshape(B, -1), o["zhat"], **ZT)
+
+
+def test_stagewise_batch_rule_equals_oracle_on_mpc_batch():
+    """The batch-coupled stop on an MPC batch that triggers it early (I* < max_iter, most problems
+    flagged): the stage-wise kernels' finish pass (copy of the right snapshot) against the CPU oracle,
+    which runs the reference's rule literally; and the per-problem mode against the same within the
+    float tolerance."""
+    from diff_qp_mpc_amd import qp as qpmod
+    n, m, T, B = 4, 2, 6, 64
+    data = problem(n, m, T, B, seed=99, active=0.2)
+    Q, p, G, h, A, b = assemble(*data)
+    o = oracle.dense_forward(Q, p, G, h, A, b)
+    assert o["iters"] < 20                                     # the rule fired before max_iter
+    tau_b, _, _ = run_fused(n, m, T, data)
+    np.testing.assert_allclose(tau_b.reshape(B, -1), o["zhat"], **ZT)
+    old = qpmod.TERMINATION
+    qpmod.TERMINATION = "per_problem"
+    try:
+        tau_p, _, _ = run_fused(n, m, T, data)
+    finally:
+        qpmod.TERMINATION = old
+    np.testing.assert_allclose(tau_p.reshape(B, -1), o["zhat"], rtol=1e-5, atol=1e-7)
