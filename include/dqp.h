@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define DQP_VERSION 200 /* 0.2.0: dqp_qp_forward takes a termination buffer */
+#define DQP_VERSION 210 /* 0.2.1: dqp_mpc_qp_backward takes C and F, dqp_mpc_dims.dyn_id, dqp_mpc_qp_termination_bytes,
+                           dqp_al_newton_solve_bytes(dims, banded) */
 #define DQP_MAX_DIM 64
 
 enum {
