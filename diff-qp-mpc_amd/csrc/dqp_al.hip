@@ -616,6 +616,11 @@ struct LsAP {
     double *merit;
     double dt;
     int B, n, m, T, ncand, dyn;
+    // optional: selection folded into the group kernel (argmin, acceptance, update of the iterate;
+    // al_utils.py:516-526) when one group sees all candidates of its problem
+    double *xu_w, *merit_cur, *status;
+    int32_t *fail;
+    const int32_t *info;
 };
 
 // merit (al_utils.py:37-59) of ncand candidates xu + 2^-k upd per problem (x_0 pinned to x0,
@@ -728,6 +733,10 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
 #pragma unroll
     for (int j = 0; j < n; ++j) ly[j] = (r < T - 1) ? lam[r * n + j] : 0.0;
     // candidates k = blockIdx.y, blockIdx.y + gridDim.y, ...: small batches are split over more wavefronts
+    const bool fold = P.xu_w != nullptr && gridDim.y == 1 && P.ncand > 0;
+    double best = 0.0;
+    int arg = 0;
+    bool isnan_ = false;
     for (int k = blockIdx.y; k < nc; k += gridDim.y) {
         const double step = P.ncand > 0 ? (double)exp2f(-(float)k) : 0.0;    // float steps, as the reference
         double acc = 0.0;
@@ -758,7 +767,32 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
         }
         __syncthreads();
         acc = group_sum<TPI>(acc);
-        if (r == 0 && live) P.merit[(long long)k * P.B + b] = acc;
+        if (fold) {             // torch.min over the candidates: NaN wins, else the first minimum
+            if (k == 0) { best = acc; arg = 0; isnan_ = acc != acc; }
+            else if (!isnan_) {
+                if (acc != acc) { best = acc; arg = k; isnan_ = true; }
+                else if (acc < best) { best = acc; arg = k; }
+            }
+        } else if (r == 0 && live) {
+            P.merit[(long long)k * P.B + b] = acc;
+        }
+    }
+    if (fold) {
+        const bool take = best < P.merit_cur[b];
+        if (r == 0 && live) {
+            P.merit_cur[b] = best;                              // new_merit regardless of acceptance
+            if (P.status) P.status[b] = take ? 1.0 : 0.0;
+            if (P.info && P.info[b] != 0) atomicOr(P.fail, 1);  // Cholesky failed: the caller re-runs the slow path
+        }
+        if (take && live) {
+            const double sb = (double)exp2f(-(float)arg);
+            double *xw = P.xu_w + b * (long long)nzq;
+#pragma unroll
+            for (int i = 0; i < nt; ++i) {
+                const int e = r + TPI * i;
+                if (e < nzq) xw[e] = fma(sb, eu[i], ex[i]);
+            }
+        }
     }
 }
 
@@ -771,7 +805,7 @@ template <class Map, int TPI> int launch_ls_group(const LsAP &P, hipStream_t st)
     unsigned split = 1;
     if (P.ncand > 1) while (split < 4 && (unsigned long long)blocks * 4 * split < 2048) split *= 2;
     hipLaunchKernelGGL((al_ls_group_kernel<Map, TPI>), dim3(blocks, split), dim3(256), lds, st, P);
-    return DQP_OK;
+    return (P.xu_w && split == 1 && P.ncand > 0) ? 2 : DQP_OK;     // 2: the selection happened in the kernel
 }
 
 template <class Map> int launch_ls_t(const LsAP &P, hipStream_t st)
@@ -1037,11 +1071,14 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
             int rc = dqp_al_banded_newton_step(d, dyn_id, dt, xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, upd, L,
                                                info, stream);
             if (rc) return rc;
-            LsAP Lc = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, dt, B, n, m, T, 20, dyn_id};
+            LsAP Lc = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, dt, B, n, m, T, 20, dyn_id,
+                       xu, merit_cur, status, fail, info};
             rc = launch_ls(Lc, st);
-            if (rc) return rc;
-            SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
-            hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
+            if (rc != DQP_OK && rc != 2) return rc;
+            if (rc != 2) {          // candidates split over several groups: select in a launch of its own
+                SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
+                hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
+            }
         }
         return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
     }
