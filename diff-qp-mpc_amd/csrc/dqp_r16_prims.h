@@ -424,6 +424,47 @@ __device__ __forceinline__ void vec_get(const double *P, double (&v)[S], int n, 
 }
 
 // Row-distributed load of an nrows x NC matrix (rows beyond nrows are zero).
+// The same row-distributed load staged through LDS: the 16 lanes of a QP copy the contiguous matrix
+// with 16 bytes per lane -- 256 contiguous bytes per load instruction and QP, instead of 16 rows 8 NC
+// bytes apart (64 distinct cache lines per instruction over the four QPs of a wavefront) -- one register
+// slot (16 rows) at a time, and each lane reads its row back from LDS.  `stage` needs 16 NC doubles.
+// V2: the matrix starts on a 16-byte boundary for every QP (rows x NC even).
+template <int S, int NC, bool V2>
+__device__ __forceinline__ void load_rows_staged(const double *src, int nrows, double (&dst)[S][NC], int r, double *stage)
+{
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int nr = nrows - 16 * s < 16 ? nrows - 16 * s : 16;       // rows of this slot
+        const double *blk = src + 16 * s * NC;
+        if (V2 && (reinterpret_cast<unsigned long long>(blk) & 15ull) == 0) {      // (a view may start on an 8-byte boundary)
+            const double2 *b2 = reinterpret_cast<const double2 *>(blk);
+            double2 *s2 = reinterpret_cast<double2 *>(stage);
+#pragma unroll
+            for (int k = 0; k < (16 * NC / 2 + 15) / 16; ++k) {
+                const int e = r + 16 * k;
+                if (e < nr * NC / 2) s2[e] = b2[e];
+            }
+            if ((nr * NC) & 1) { if (r == 0) stage[nr * NC - 1] = blk[nr * NC - 1]; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int e = r + 16 * k;
+                if (e < nr * NC) stage[e] = blk[e];
+            }
+        }
+        __syncthreads();
+        const double *row = stage + (r < nr ? r : 0) * NC;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) dst[s][j] = row[j];
+        if (16 * s + 15 >= nrows) {
+            const double keep = r < nr ? 1.0 : 0.0;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) dst[s][j] *= keep;
+        }
+        __syncthreads();
+    }
+}
+
 template <int S, int NC>
 __device__ __forceinline__ void load_rows(const double *src, int nrows, double (&dst)[S][NC], int r)
 {

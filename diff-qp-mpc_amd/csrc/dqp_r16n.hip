@@ -74,6 +74,14 @@ template <int N_, int M_, int E_> struct Cfg {
     static constexpr int oDummy = oBc + 2;              // 16 write-only sink slots
     static constexpr int ldsQP = oDummy + 16;
     static constexpr int ldsQPpad = (ldsQP + 1) & ~1;
+#ifndef DQP_R16N_STAGED
+#define DQP_R16N_STAGED 0
+#endif
+    // Q, G, A through LDS with coalesced 16-byte-per-lane loads (a slot of 16 rows must fit the LDS behind
+    // the packed Lq).  Measured at the metric size, B = 4096: 226.3 us per launch against 217.0 us with each lane
+    // streaming its own row (load_rows) -- the copy, the two LDS hops and their waits cost more than the 4x
+    // fewer cache-line lookups save -- so it stays off; -DDQP_R16N_STAGED=1 builds it.
+    static constexpr bool STAGED = DQP_R16N_STAGED && 16 * N_ <= ldsQP - oTl;
     __host__ __device__ static constexpr int toff(int k) { return k * (N_ - E_) + k * (k - 1) / 2; }
     // caller workspace per QP (doubles): the reflector tails (parked during the iteration), then
     // the factorisation context the backward pass restarts from -- what the reference keeps on
@@ -449,6 +457,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     {   // A: Q -> Lq -> packed LDS
         double Lq[SN][N];
         if (mpc) mpc_rows_Q<SN, N>(P, qp, Lq, r);
+        else if (C::STAGED) load_rows_staged<SN, N, (N * N) % 2 == 0>(P.Q + qp * P.sQ, N, Lq, r, lds + C::oTl);
         else load_rows<SN, N>(P.Q + qp * P.sQ, N, Lq, r);
         if (!chol_rows<SN, N>(Lq, st.rdq, r)) st.status = DQP_STATUS_Q_NOT_PD;
         tri_store<SN, N>(lds + C::oLq, Lq, r, dummy);
@@ -472,8 +481,13 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
         if (!C::SPLIT) mpc_rows_G<SM, N>(P, M, st.Gh, r);
         if (E > 0) mpc_rows_A<SE, N>(P, qp, E, st.Ah, r);
     } else {
-        if (!C::SPLIT) load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
-        if (E > 0) load_rows<SE, N>(P.A + qp * P.sA, E, st.Ah, r);
+        if (C::STAGED) {
+            if (!C::SPLIT) load_rows_staged<SM, N, (M * N) % 2 == 0>(P.G + qp * P.sG, M, st.Gh, r, lds + C::oTl);
+            if (E > 0) load_rows_staged<SE, N, (C::EC * N) % 2 == 0>(P.A + qp * P.sA, E, st.Ah, r, lds + C::oTl);
+        } else {
+            if (!C::SPLIT) load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
+            if (E > 0) load_rows<SE, N>(P.A + qp * P.sA, E, st.Ah, r);
+        }
     }
     {
         const double *Lp = lds + C::oLq;
@@ -635,6 +649,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
     if (C::SPLIT) {
         // B, C for G on its own: Gh = G Lq^-T, then the reflectors (tails in LDS, read row-uniformly)
         if (mpc) mpc_rows_G<SM, N>(P, M, st.Gh, r);
+        else if (C::STAGED) load_rows_staged<SM, N, (M * N) % 2 == 0>(P.G + qp * P.sG, M, st.Gh, r, lds + C::oTl);
         else load_rows<SM, N>(P.G + qp * P.sG, M, st.Gh, r);
         const double *Lp = relabel(lds + C::oLq);
 #pragma unroll
