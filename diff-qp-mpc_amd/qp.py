@@ -97,6 +97,9 @@ def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim, terminat
     assert neq > 0 or nineq > 0                                   # qp.py:90
     dev = Q.device
     dims = _lib.dqp_dims(nBatch, nz, nineq, neq, sQ, sp, sG, sh, sA, sb)
+    if termination == "batch" and not (1 <= maxIter <= 64):
+        raise ValueError("the batch-coupled termination replays the stop rule on 64-bit iteration masks: 1 <= maxIter <= 64 "
+                         "(got %d); use termination='per_problem' for longer runs" % maxIter)
     flags = FORCE_FLAGS | (_lib.DQP_FLAG_BATCH_TERMINATION if termination == "batch" else 0)
     opts = _lib.dqp_opts(eps, STALL_TOL, maxIter, notImprovedLim, flags, 0)
     if dyn is not None:          # true-dynamics residual on chip (include/dqp.h: dqp_opts.dyn_*)
