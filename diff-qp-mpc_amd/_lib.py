@@ -41,7 +41,7 @@ DQP_MAX_DIM = 64
 
 # every symbol include/dqp.h declares
 SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termination_bytes",
-           "dqp_qp_forward", "dqp_qp_backward", "dqp_mpc_assemble", "dqp_mpc_assemble_backward",
+           "dqp_qp_forward", "dqp_qp_backward", "dqp_term_local_masks", "dqp_qp_forward_finish", "dqp_mpc_assemble", "dqp_mpc_assemble_backward",
            "dqp_mpc_qp_supported", "dqp_mpc_qp_workspace_bytes", "dqp_mpc_qp_termination_bytes", "dqp_mpc_qp_forward", "dqp_mpc_qp_backward", "dqp_mpc_line_search", "dqp_mpc_rollout_backward",
            "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble", "dqp_al_merit",
            "dqp_al_newton_solve_bytes", "dqp_al_newton_solve",
@@ -97,6 +97,10 @@ def load():
     lib.dqp_termination_bytes.restype = ctypes.c_size_t
     lib.dqp_termination_bytes.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)]
     lib.dqp_qp_forward.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 15
+    lib.dqp_term_local_masks.restype = ctypes.c_int
+    lib.dqp_term_local_masks.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 3
+    lib.dqp_qp_forward_finish.restype = ctypes.c_int
+    lib.dqp_qp_forward_finish.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 16
     lib.dqp_qp_backward.restype = ctypes.c_int
     lib.dqp_qp_backward.argtypes = [ctypes.POINTER(dqp_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 17
     lib.dqp_mpc_assemble.restype = ctypes.c_int

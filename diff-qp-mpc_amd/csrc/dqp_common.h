@@ -80,6 +80,8 @@ __device__ __forceinline__ void term_zero_acc(const KParams &P)
 // batch rule replay + redo list (dqp_term.hip); 0 on success
 size_t term_bytes(int B, int maxIter, int snapDim);
 int term_decide(const KParams &P, void *term, void *stream);
+int term_local_masks(const KParams &P, void *term, unsigned long long *masks, void *stream);
+int term_decide_global(const KParams &P, void *term, const unsigned long long *masks, void *stream);
 void term_bind_pass1(KParams &P, void *term, int snapDim);
 void term_bind_pass2(KParams &P, void *term);
 

@@ -816,6 +816,48 @@ dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, cons
     return forward_once(P, lds, workspace, stream);
 }
 
+// ---- the batch rule over a batch that is sharded across devices (include/dqp.h)
+__attribute__((visibility("default"))) int
+dqp_term_local_masks(const dqp_dims *dims, const dqp_opts *opts, void *termination, uint64_t *masks, void *stream)
+{
+    KParams P = {};
+    size_t lds = 0;
+    int rc = fill_params(dims, opts, P, lds);
+    if (rc != DQP_OK) return rc;
+    if (!(P.flags & DQP_FLAG_BATCH_TERMINATION) || !termination || !masks || P.maxIter < 1 || P.maxIter > 64)
+        return DQP_ERR_BAD_ARG;
+    if (P.B == 0) return hipMemsetAsync(masks, 0, 24, (hipStream_t)stream) == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+    P.eps = opts ? opts->eps : 1e-12;
+    return term_local_masks(P, termination, (unsigned long long *)masks, stream);
+}
+
+__attribute__((visibility("default"))) int
+dqp_qp_forward_finish(const dqp_dims *dims, const dqp_opts *opts, const double *Q, const double *p,
+                      const double *G, const double *h, const double *A, const double *b, double *zhat,
+                      double *lam, double *nu, double *slack, int32_t *info, double *best_resid,
+                      void *workspace, void *termination, const uint64_t *masks, void *stream)
+{
+    KParams P = {};
+    size_t lds = 0;
+    int rc = fill_params(dims, opts, P, lds);
+    if (rc != DQP_OK) return rc;
+    if (P.B == 0) return DQP_OK;
+    if (!(P.flags & DQP_FLAG_BATCH_TERMINATION) || !termination || !masks || P.maxIter < 1 || P.maxIter > 64)
+        return DQP_ERR_BAD_ARG;
+    if (!Q || !p || !G || !h || !zhat || !lam || !slack) return DQP_ERR_BAD_ARG;
+    if (P.E > 0 && (!A || !b || !nu)) return DQP_ERR_BAD_ARG;
+    P.workspace = (double *)workspace;
+    P.Q = Q; P.p = p; P.G = G; P.h = h; P.A = A; P.b = b;
+    P.zhat = zhat; P.lam = lam; P.nu = nu; P.slack = slack;
+    P.info = info; P.best_resid = best_resid;
+    P.eps = opts ? opts->eps : 1e-12;
+    const bool nullspace = workspace && !(P.flags & (DQP_FLAG_GENERIC_ONLY | DQP_FLAG_NO_NULLSPACE)) && !P.dynId;
+    term_bind_pass1(P, termination, nullspace ? r16n_snapshot_doubles(P.N, P.M, P.E) : 0);    // (snapshot pointer)
+    if ((rc = term_decide_global(P, termination, (const unsigned long long *)masks, stream)) != DQP_OK) return rc;
+    term_bind_pass2(P, termination);
+    return forward_once(P, lds, workspace, stream);
+}
+
 static int forward_once(const KParams &P, size_t lds, void *workspace, void *stream)
 {
     int rc;

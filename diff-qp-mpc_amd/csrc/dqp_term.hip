@@ -49,7 +49,8 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
 // to finish replays the reference's rule on the masks and writes I* and the redo flags
 // (hdr[0], hdr[1], hdr[TERM_HDR + qp]; hdr[2] is the arrival counter).
 __global__ __launch_bounds__(256) void term_scan_kernel(const double2 *hist, Acc *acc, int32_t *hdr,
-                                                        int B, int maxIter, int notImprovedLim, double eps)
+                                                        int B, int maxIter, int notImprovedLim, double eps,
+                                                        int decide)
 {
     __shared__ unsigned long long s_m[3][4];
     __shared__ int s_last, s_istop;
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256) void term_scan_kernel(const double2 *hist, Acc
         unsigned long long *dst = tid == 0 ? &acc->improved : (tid == 1 ? &acc->notbelow : &acc->notabove);
         if (m) atomicOr(dst, m);
     }
+    if (!decide) return;            // multi-device form: the masks are combined across devices first
     // ---- last block: the rule itself
     __threadfence();
     __syncthreads();
@@ -104,6 +106,35 @@ __global__ __launch_bounds__(256) void term_scan_kernel(const double2 *hist, Acc
     int nredo = 0;
     for (long long q = tid; q < B; q += blockDim.x) {
         const int redo = __hip_atomic_load(&argbest[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= istop ? 1 : 0;
+        argbest[q] = redo;
+        nredo += redo;
+    }
+    if (nredo) atomicAdd(&hdr[1], nredo);
+}
+
+// The rule on given masks (multi-device form: the OR of every shard's masks), then this shard's redo
+// flags; one workgroup.
+__global__ __launch_bounds__(256) void term_decide_kernel(const unsigned long long *masks, int32_t *hdr, int B,
+                                                          int maxIter, int notImprovedLim)
+{
+    __shared__ int s_istop;
+    int32_t *argbest = hdr + TERM_HDR;
+    if (threadIdx.x == 0) {
+        const unsigned long long ai = masks[0], anb = masks[1], ana = masks[2];
+        int istop = maxIter, nNot = 0;
+        for (int it = 0; it < maxIter; ++it) {
+            if (it == 0 || ((ai >> it) & 1ull)) nNot = 0;
+            else nNot += 1;
+            if (nNot == notImprovedLim || !((anb >> it) & 1ull) || !((ana >> it) & 1ull)) { istop = it + 1; break; }
+        }
+        s_istop = istop;
+        hdr[0] = istop;
+    }
+    __syncthreads();
+    const int istop = s_istop;
+    int nredo = 0;
+    for (long long q = threadIdx.x; q < B; q += blockDim.x) {
+        const int redo = argbest[q] >= istop ? 1 : 0;
         argbest[q] = redo;
         nredo += redo;
     }
@@ -148,7 +179,28 @@ int term_decide(const KParams &P, void *term, void *stream)
     const int blocks = (P.B + 255) / 256;
     hipLaunchKernelGGL(term_scan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                        (const double2 *)term, acc_of(term, P.B, P.maxIter), hdr_of(term, P.B, P.maxIter),
-                       P.B, P.maxIter, P.notImprovedLim, P.eps);
+                       P.B, P.maxIter, P.notImprovedLim, P.eps, 1);
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+// multi-device form, step 1: this shard's three iteration masks -> masks[3] (device memory)
+int term_local_masks(const KParams &P, void *term, unsigned long long *masks, void *stream)
+{
+    const int blocks = (P.B + 255) / 256;
+    hipLaunchKernelGGL(term_scan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const double2 *)term, acc_of(term, P.B, P.maxIter), hdr_of(term, P.B, P.maxIter),
+                       P.B, P.maxIter, P.notImprovedLim, P.eps, 0);
+    if (hipMemcpyAsync(masks, acc_of(term, P.B, P.maxIter), 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                       (hipStream_t)stream) != hipSuccess)
+        return DQP_ERR_LAUNCH;
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+}
+
+// multi-device form, step 2: the rule on the combined masks, this shard's redo flags
+int term_decide_global(const KParams &P, void *term, const unsigned long long *masks, void *stream)
+{
+    hipLaunchKernelGGL(term_decide_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, masks,
+                       hdr_of(term, P.B, P.maxIter), P.B, P.maxIter, P.notImprovedLim);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 

@@ -38,6 +38,9 @@ STALL_TOL = 1e-10
 # "batch": DQP_FLAG_BATCH_TERMINATION, the reference's stopping rule replayed over the batch (the
 # default of every operator in this package); "per_problem": each problem stops on its own
 TERMINATION = "batch"
+# shards of one logical batch: a callable int64[3] -> int64[3] that ORs the batch rule's iteration masks over
+# the shards (sharding.global_batch_rule sets it); None: the rule couples the batch this call is given
+MASK_EXCHANGE = None
 # extra dqp_opts.flags OR-ed into every call (tests use DQP_FLAG_GENERIC_ONLY / _NO_NULLSPACE to
 # pin a kernel family; 0 = automatic dispatch)
 FORCE_FLAGS = 0
@@ -119,12 +122,28 @@ def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim, terminat
     ws = torch.empty(wsb // 8, **kw) if wsb > 0 else None
     tb = int(lib.dqp_termination_bytes(ctypes.byref(dims), ctypes.byref(opts)))
     term = torch.empty((tb + 7) // 8, **kw) if tb > 0 else None
-    with torch.cuda.device(dev):
-        rc = lib.dqp_qp_forward(ctypes.byref(dims), ctypes.byref(opts), _ptr(Q), _ptr(p), _ptr(G),
-                                _ptr(h), _ptr(A), _ptr(b), _ptr(zhat), _ptr(lam), _ptr(nu),
-                                _ptr(slack), _ptr(info), _ptr(resid), _ptr(ws), _ptr(term),
-                                _stream(dev))
-    _lib.check(rc, "dqp_qp_forward")
+    args = (_ptr(Q), _ptr(p), _ptr(G), _ptr(h), _ptr(A), _ptr(b), _ptr(zhat), _ptr(lam), _ptr(nu), _ptr(slack),
+            _ptr(info), _ptr(resid), _ptr(ws), _ptr(term))
+    if termination == "batch" and MASK_EXCHANGE is not None:
+        # this batch is a shard of a larger one (sharding.global_batch_rule): pass 1, this shard's three
+        # iteration masks, the caller's OR over the shards (24 bytes), the rule on the combined masks, pass 2
+        opts1 = _lib.dqp_opts(eps, STALL_TOL, maxIter, notImprovedLim, flags | _lib.DQP_FLAG_HISTORY_ONLY, 0)
+        if dyn is not None:
+            opts1.dyn_id, opts1.dyn_T, opts1.dyn_dt, opts1.dyn_x0 = opts.dyn_id, opts.dyn_T, opts.dyn_dt, opts.dyn_x0
+        masks = torch.zeros(3, dtype=torch.int64, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.dqp_qp_forward(ctypes.byref(dims), ctypes.byref(opts1), *args, _stream(dev))
+            _lib.check(rc, "dqp_qp_forward (pass 1)")
+            _lib.check(lib.dqp_term_local_masks(ctypes.byref(dims), ctypes.byref(opts), _ptr(term), _ptr(masks),
+                                                _stream(dev)), "dqp_term_local_masks")
+        masks = MASK_EXCHANGE(masks).contiguous()
+        with torch.cuda.device(dev):
+            rc = lib.dqp_qp_forward_finish(ctypes.byref(dims), ctypes.byref(opts), *args, _ptr(masks), _stream(dev))
+        _lib.check(rc, "dqp_qp_forward_finish")
+    else:
+        with torch.cuda.device(dev):
+            rc = lib.dqp_qp_forward(ctypes.byref(dims), ctypes.byref(opts), *args, _stream(dev))
+        _lib.check(rc, "dqp_qp_forward")
     # the workspace now holds the factorisation context backward can restart from (include/dqp.h)
     # (only the null-space kernels leave one: not the forced families, not the true-dynamics path)
     ctx_ws = ws if (ws is not None and dyn is None and

@@ -70,6 +70,39 @@ def gather_solution_autograd(z_local, nbatch, group=None):
     return _GatherWithGrad.apply(z_local, nbatch, group)
 
 
+class global_batch_rule:
+    """Context manager: inside it QPFunction / DenseQPFunction evaluate the reference's batch-coupled stop
+    (batch.py:119-144) over the WHOLE sharded batch instead of this rank's shard -- one extra collective,
+    a bitwise-OR all_reduce of three int64 iteration masks (24 bytes), between pass 1 and the decision
+    (include/dqp.h: dqp_term_local_masks / dqp_qp_forward_finish).  Results on the shards are then bit-identical
+    to a single-device solve of the concatenated batch.
+
+        with sharding.global_batch_rule(group):
+            z_local = QPFunction()(Q[lo:hi], p[lo:hi], G[lo:hi], h[lo:hi], A[lo:hi], b[lo:hi])
+    """
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def _exchange(self, masks):
+        if dist.get_backend(self.group) == "gloo" and masks.is_cuda:      # (CPU rehearsal of the RCCL path)
+            host = masks.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.BOR, group=self.group)
+            return host.to(masks.device)
+        dist.all_reduce(masks, op=dist.ReduceOp.BOR, group=self.group)
+        return masks
+
+    def __enter__(self):
+        from . import qp
+        self._old, qp.MASK_EXCHANGE = qp.MASK_EXCHANGE, self._exchange
+        return self
+
+    def __exit__(self, *exc):
+        from . import qp
+        qp.MASK_EXCHANGE = self._old
+        return False
+
+
 def reduce_shared_grad_from_local_mean(g_local_mean, n_local, nbatch, group=None):
     """QPFunction.backward hands back the LOCAL `.mean(0)` for a parameter shared by the batch
     (qp.py:160-178 semantics on this rank's shard).  The reference's value on the full batch is the

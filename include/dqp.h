@@ -129,6 +129,25 @@ size_t dqp_workspace_bytes(const dqp_dims *dims);
 size_t dqp_termination_bytes(const dqp_dims *dims, const dqp_opts *opts);
 
 /*
+ * The batch-coupled rule over a batch that is SHARDED across devices (the reference's rule couples every
+ * sample of the batch it is given, batch.py:119-144; shards of one logical batch can reproduce the stop of
+ * the whole batch with one 24-byte exchange):
+ *   1. dqp_qp_forward(flags | DQP_FLAG_BATCH_TERMINATION | DQP_FLAG_HISTORY_ONLY) on every shard;
+ *   2. dqp_term_local_masks -> masks[3] (device memory): bit `it` of masks[0] = some problem of the shard
+ *      improved at iteration it, of masks[1] = some problem has not best_resid < eps, of masks[2] = some problem
+ *      has not mu > 1e32;
+ *   3. the caller ORs the masks over the shards (e.g. all_reduce(op=BOR) on an int64 tensor);
+ *   4. dqp_qp_forward_finish with the combined masks: the rule, then pass 2 of this shard.
+ * With the masks of a single shard step 2-4 equal what dqp_qp_forward does in one call.
+ */
+int dqp_term_local_masks(const dqp_dims *dims, const dqp_opts *opts, void *termination, uint64_t *masks,
+                         void *stream);
+int dqp_qp_forward_finish(const dqp_dims *dims, const dqp_opts *opts, const double *Q, const double *p,
+                          const double *G, const double *h, const double *A, const double *b, double *zhat,
+                          double *lam, double *nu, double *slack, int32_t *info, double *best_resid,
+                          void *workspace, void *termination, const uint64_t *masks, void *stream);
+
+/*
  * Replaces: qpth.qp.QPFunction(...).forward  (qpth/qp.py:24-126) =
  *           pdipm_b.pre_factor_kkt + pdipm_b.forward (qpth/solvers/pdipm/batch.py:377-428,
  *           46-208), with dyn_res(x) = A x - b and cost_grad(x) = Q x + p; and the forward of

@@ -354,3 +354,41 @@ def test_empty_batch_and_bad_dims(dqp):
     assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 15)) == -1      # nineq == 0
     d = _lib.dqp_dims(0, 5, 3, 0, 0, 0, 0, 0, 0, 0)
     assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 15)) == 0       # empty batch
+
+
+@pytest.mark.parametrize("kind", ["M", "R"])
+def test_global_batch_rule_over_shards(dqp, kind):
+    """The batch-coupled stop over a batch that is split across devices (include/dqp.h:
+    dqp_term_local_masks / dqp_qp_forward_finish; sharding.global_batch_rule): two shards solved
+    separately with their iteration masks OR-ed in between give bit-identical results to the single solve
+    of the whole batch; with shard-local rules they need not (family M: the rule fires early and at
+    different iterations per shard)."""
+    from diff_qp_mpc_amd import qp as qpmod
+    from families import family, family_mpc
+    B = 96
+    ins = [dev(a, grad=False) for a in (family_mpc(3, B) if kind == "M" else family(3, B, 30, 30, 15, "R"))]
+    whole = qpmod._forward_impl(*ins, 1e-12, 20, 3, termination="batch")
+    torch.cuda.synchronize()
+    cut = 40                                              # ragged shards
+    shards = [[t[:cut] for t in ins], [t[cut:] for t in ins]]
+    # the exchange: both shards' masks OR-ed.  One process plays both ranks, so the first pass collects the
+    # local masks and the second pass hands every shard the combined ones.
+    seen = []
+    def collect(m):
+        seen.append(m.clone())
+        return m
+    old = qpmod.MASK_EXCHANGE
+    try:
+        qpmod.MASK_EXCHANGE = collect
+        for sh in shards:
+            qpmod._forward_impl(*sh, 1e-12, 20, 3, termination="batch")
+        combined = seen[0] | seen[1]
+        qpmod.MASK_EXCHANGE = lambda m: combined.clone()
+        outs = [qpmod._forward_impl(*sh, 1e-12, 20, 3, termination="batch") for sh in shards]
+    finally:
+        qpmod.MASK_EXCHANGE = old
+    torch.cuda.synchronize()
+    for k in range(4):                                     # zhat, lam, nu, slack
+        got = torch.cat([o[k] for o in outs], 0)
+        assert torch.equal(got, whole[k]), "output %d differs from the single-batch solve" % k
+    assert torch.equal(torch.cat([o[4] for o in outs], 0)[:, 1], whole[4][:, 1])        # iterations
