@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define DQP_VERSION 210 /* 0.2.1: dqp_mpc_qp_backward takes C and F, dqp_mpc_dims.dyn_id, dqp_mpc_qp_termination_bytes,
+#define DQP_VERSION 211 /* 0.2.1x: dqp_mpc_qp_backward takes C and F, dqp_mpc_dims.dyn_id, dqp_mpc_qp_termination_bytes,
+                           dqp_term_local_masks + dqp_qp_forward_finish,
                            dqp_al_newton_solve_bytes(dims, banded) */
 #define DQP_MAX_DIM 64
 
