@@ -40,7 +40,11 @@ def _worker(rank, world, port, B, q):
 
 
 def test_two_ranks_global_batch_rule_bitwise():
-    B, world, port = 90, 2, 29533
+    import socket
+    with socket.socket() as sk:             # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    B, world = 90, 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, B, q)) for r in range(world)]
