@@ -83,3 +83,43 @@ def test_dl_dA():
 def test_dl_db():
     d, truez = problem(nz=10, neq=3, nineq=1, Qscale=100., Gscale=100., Ascale=100.)
     np.testing.assert_allclose(numeric(d, truez, "b"), analytic(d, truez)["b"], rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("family_flag", ["auto", "rows", "generic"])
+def test_kkt_solver_against_a_dense_solve(family_flag):
+    """The reference's test_lu_kkt_solver / test_ir_kkt_solver (test.py:190-247) compare its block KKT solve
+    with a dense LU of the full KKT matrix on a random problem.  Here: the one KKT solve of the backward
+    kernels (every family) at an arbitrary interior point (s, z > 0, not a solution) against numpy's dense
+    solve of  [Q 0 G' A'; 0 D I 0; G I 0 0; A 0 0 0] [dx ds dz dy] = -[g 0 0 0],  D = z/s  -- the gradients
+    the kernels return are dp = dx, dh = -dz, db = -dy (qp.py:143-178)."""
+    from diff_qp_mpc_amd import qp as qpmod, _lib
+    rng = np.random.default_rng(0)
+    B, nz, nineq, neq = 5, 30, 30, 15
+    L = rng.standard_normal((B, nz, nz))
+    Q = L @ L.transpose(0, 2, 1) + 1e-3 * np.eye(nz)
+    G = rng.standard_normal((B, nineq, nz)); A = rng.standard_normal((B, neq, nz))
+    s = rng.random((B, nineq)) + 0.1; z = rng.random((B, nineq)) + 0.1
+    zhat = rng.standard_normal((B, nz)); nu = rng.standard_normal((B, neq)); g = rng.standard_normal((B, nz))
+    dp_ref = np.zeros((B, nz)); dh_ref = np.zeros((B, nineq)); db_ref = np.zeros((B, neq))
+    for i in range(B):
+        D = np.diag(z[i] / s[i])
+        Z = np.zeros
+        K = np.block([[Q[i], Z((nz, nineq)), G[i].T, A[i].T],
+                      [Z((nineq, nz)), D, np.eye(nineq), Z((nineq, neq))],
+                      [G[i], np.eye(nineq), Z((nineq, nineq)), Z((nineq, neq))],
+                      [A[i], Z((neq, nineq)), Z((neq, nineq)), Z((neq, neq))]])
+        sol = np.linalg.solve(K, -np.concatenate([g[i], np.zeros(2 * nineq + neq)]))
+        dp_ref[i] = sol[:nz]; dh_ref[i] = -sol[nz + nineq:nz + 2 * nineq]; db_ref[i] = -sol[nz + 2 * nineq:]
+    t = lambda a: torch.tensor(a, dtype=torch.float64, device="cuda")
+    old = qpmod.FORCE_FLAGS
+    qpmod.FORCE_FLAGS = {"auto": 0, "rows": _lib.DQP_FLAG_NO_NULLSPACE, "generic": _lib.DQP_FLAG_GENERIC_ONLY}[family_flag]
+    try:
+        dims = _lib.dqp_dims(B, nz, nineq, neq, nz * nz, nz, nineq * nz, nineq, neq * nz, neq)
+        out = qpmod._backward_impl((t(Q), t(G), t(A), dims, None), t(zhat), t(z), t(nu), t(s), t(g), (True,) * 6,
+                                   _lib.DQP_FLAG_DENSE_BACKWARD)
+    finally:
+        qpmod.FORCE_FLAGS = old
+    dQ, dp, dG, dh, dA, db = [o.cpu().numpy() for o in out]
+    np.testing.assert_allclose(dp, dp_ref, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(dh, dh_ref, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(db, db_ref, rtol=1e-8, atol=1e-10)
