@@ -284,3 +284,45 @@ def test_stagewise_batch_rule_equals_oracle_on_mpc_batch():
     finally:
         qpmod.TERMINATION = old
     np.testing.assert_allclose(tau_p.reshape(B, -1), o["zhat"], rtol=1e-5, atol=1e-7)
+
+
+def test_riccati_kkt_solve_against_a_dense_solve():
+    """One KKT solve of the stage-wise kernels (dqp_mpc_qp_backward: Riccati factorisation with d = lam/slack,
+    right-hand side (g, 0, 0, 0)) at an arbitrary interior point against numpy's dense solve of the assembled
+    KKT matrix: dc = dx, df_t = dnu_t, dx0 = -dnu_init (n 12, m 4, T 8: a 408 x 408 system)."""
+    from diff_qp_mpc_amd import _lib
+    n, m, T, B = 12, 4, 8, 4
+    nt = n + m
+    C, c, F, f, x0, lo, hi = problem(n, m, T, B, seed=21)
+    Q, p, G, h, A, b = assemble(C, c, F, f, x0, lo, hi)
+    rng = np.random.default_rng(5)
+    nz, nineq, neq = T * nt, 2 * T * m, T * n
+    s = rng.random((B, nineq)) + 0.1; z = rng.random((B, nineq)) + 0.1
+    tau = rng.standard_normal((B, T, nt)); nu = rng.standard_normal((B, neq)); g = rng.standard_normal((B, T, nt))
+    dx_ref = np.zeros((B, nz)); dy_ref = np.zeros((B, neq))
+    for i in range(B):
+        D = np.diag(z[i] / s[i])
+        Z = np.zeros
+        K = np.block([[Q[i], Z((nz, nineq)), G[i].T, A[i].T],
+                      [Z((nineq, nz)), D, np.eye(nineq), Z((nineq, neq))],
+                      [G[i], np.eye(nineq), Z((nineq, nineq)), Z((nineq, neq))],
+                      [A[i], Z((neq, nineq)), Z((neq, nineq)), Z((neq, neq))]])
+        sol = np.linalg.solve(K, -np.concatenate([g[i].reshape(-1), np.zeros(2 * nineq + neq)]))
+        dx_ref[i] = sol[:nz]; dy_ref[i] = sol[nz + 2 * nineq:]
+    lib = _lib.load()
+    dims = _lib.dqp_mpc_dims(B, n, m, T, 1, 0)
+    opts = _lib.dqp_opts(0.0, 0.0, 0, 0, _lib.DQP_FLAG_DENSE_BACKWARD, 0)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device="cuda")
+    Ct, Ft, taut, lamt, nut, st, gt = t(C), t(F), t(tau), t(z), t(nu), t(s), t(g)
+    kw = dict(dtype=torch.float64, device="cuda")
+    dC, dc = torch.empty(T, B, nt, nt, **kw), torch.empty(T, B, nt, **kw)
+    dF, df, dx0 = torch.empty(T - 1, B, n, nt, **kw), torch.empty(T - 1, B, n, **kw), torch.empty(B, n, **kw)
+    ws = torch.empty(int(lib.dqp_mpc_qp_workspace_bytes(ctypes.byref(dims))) // 8, **kw)
+    P = lambda x: ctypes.c_void_p(x.data_ptr())
+    rc = lib.dqp_mpc_qp_backward(ctypes.byref(dims), ctypes.byref(opts), P(Ct), P(Ft), P(taut), P(lamt), P(nut), P(st), P(gt),
+                                 P(dC), P(dc), P(dF), P(df), P(dx0), None, P(ws), None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dc.cpu().numpy().transpose(1, 0, 2).reshape(B, -1), dx_ref, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(df.cpu().numpy().transpose(1, 0, 2).reshape(B, -1), dy_ref[:, :(T - 1) * n], rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(dx0.cpu().numpy(), -dy_ref[:, (T - 1) * n:], rtol=1e-8, atol=1e-10)
