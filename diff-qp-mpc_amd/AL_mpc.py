@@ -23,6 +23,10 @@ FUSED_NEWTON_AL = True
 # (False: never look -- needed to capture a call in a hipGraph; a failed factorisation then leaves its
 # problem at the last accepted iterate)
 CHECK_CHOLESKY = True
+# caller-supplied dynamics modules: the block-tridiagonal step on the module's own Jacobians once the QP no longer
+# fits the dense Newton step (nz > 128); 0 would use it at every size
+BANDED_USER_DYNAMICS = True
+BANDED_USER_DYNAMICS_FROM_NZ = 128
 
 
 def _detach(t):
@@ -127,7 +131,19 @@ class MPC(Module):
                     lambda xi, Qi, qi: self.compute_cost(xi, Qi, qi),
                     lambda xi, Qi, qi, yi: self.merit_grad_hess(xi, Qi, qi, dx, dx_jac, x0, yi, rho_i),
                     xu, x0, lamda, rho, Qg, qg, 1e-3, 1e-6, True)
-            if device_path and torch.is_tensor(rho):
+            banded_jac = (not device_path and _fused and BANDED_USER_DYNAMICS and x.is_cuda and dx_jac is not None
+                          and self.x_lower is None and self.u_lower.numel() == self.n_ctrl
+                          and self.T * nt > BANDED_USER_DYNAMICS_FROM_NZ
+                          and al_utils.banded_jac_supported(self.n_batch, self.n_state, self.n_ctrl, self.T))
+            if banded_jac:
+                # caller-supplied dynamics at a horizon the dense Newton step cannot hold (nz > 128): its own
+                # Jacobians into the block-tridiagonal step
+                out, status, failed = al_utils.NewtonALBandedJac.apply(
+                    lambda xi, Qi, qi, yi, x0i=x0, rhoi=rho_i, grad=False:
+                        self.merit_function(xi, Qi, qi, dx, x0i, yi, rhoi, grad),
+                    dx_jac, xu, x0, lamda, rho, Q, q, self.u_lower, self.u_upper, True)
+                fail_flags.append(failed.reshape(1).to(torch.int32))
+            elif device_path and torch.is_tensor(rho):
                 # registered device model: the four Newton steps in one C-ABI call (dqp_al_newton_solve);
                 # Cholesky-failure flags are collected and checked once after the last AL iteration
                 out, status = al_utils.NewtonALDevice.apply(xu, x0, lamda, rho, Q, q, dx, self.u_lower,

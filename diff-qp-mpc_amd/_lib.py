@@ -46,6 +46,7 @@ SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termin
            "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble", "dqp_al_merit",
            "dqp_al_newton_solve_bytes", "dqp_al_newton_solve",
            "dqp_al_outer_update", "dqp_al_banded_factor_bytes", "dqp_al_banded_newton_step", "dqp_al_banded_solve",
+           "dqp_al_banded_newton_step_jac",
            "dqp_dyn_sizes", "dqp_dyn_step", "dqp_dyn_jacobian", "dqp_dyn_forward_dynamics",
            "dqp_dyn_forward_derivatives")
 DQP_DYN = {"pendulum1l": 1, "cartpole1l": 2, "cartpole2l": 3, "pendulum_euler": 4, "pendulum_dx": 5,
@@ -141,6 +142,8 @@ def load():
     lib.dqp_al_banded_factor_bytes.argtypes = [ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int]
     lib.dqp_al_banded_newton_step.restype = ctypes.c_int
     lib.dqp_al_banded_newton_step.argtypes = [ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int, ctypes.c_double] + [_dp] * 12
+    lib.dqp_al_banded_newton_step_jac.restype = ctypes.c_int
+    lib.dqp_al_banded_newton_step_jac.argtypes = [ctypes.POINTER(dqp_al_mpc_dims)] + [_dp] * 15
     lib.dqp_al_banded_solve.restype = ctypes.c_int
     lib.dqp_al_banded_solve.argtypes = [ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int] + [_dp] * 4
     i32p = ctypes.POINTER(ctypes.c_int32)

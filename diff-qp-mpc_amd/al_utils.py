@@ -387,6 +387,80 @@ class NewtonAL(torch.autograd.Function):
         return (None,) * 8 + (g * x, g, None, None, None)
 
 
+def banded_jac_supported(B, n, m, T):
+    """A block-tridiagonal Newton step exists for caller-linearised dynamics of these sizes."""
+    dims = _lib.dqp_al_mpc_dims(B, n, m, T)
+    return int(_lib.load().dqp_al_banded_factor_bytes(ctypes.byref(dims), 0)) > 0
+
+
+class NewtonALBandedJac(torch.autograd.Function):
+    """NewtonAL (al_utils.py:363-500) for a caller-supplied dynamics module at ANY horizon: the module's own
+    linearisation (x_next, (Jx, Ju)) = dx_jac(x, u) goes to dqp_al_banded_newton_step_jac -- gradient,
+    block-tridiagonal Hessian, block Cholesky and solve in one launch, no (B, ncon, nz) Jacobian and no
+    (B, nz, nz) Hessian in memory (the dense step stops at nz = 128) -- and the line search evaluates the
+    module on the 20 candidates as NewtonAL does."""
+
+    @staticmethod
+    def forward(ctx, meritfn, dx_jac, xi, x0, lam, rho, Q, q, u_lower, u_upper, ls):
+        lib = _lib.load()
+        B, T, nt = xi.shape
+        n = x0.shape[-1]
+        m = nt - n
+        dev = xi.device
+        kw = dict(dtype=torch.float64, device=dev)
+        d64 = lambda t: t.detach().double().contiguous()
+        dims = _lib.dqp_al_mpc_dims(B, n, m, T)
+        rho_t = rho if torch.is_tensor(rho) else torch.full((B,), float(rho), **kw)
+        keep = [d64(x0), d64(Q), d64(q), d64(lam), d64(rho_t).reshape(B), d64(u_lower).reshape(-1), d64(u_upper).reshape(-1)]
+        fac = torch.empty(int(lib.dqp_al_banded_factor_bytes(ctypes.byref(dims), 0)) // 8, **kw)
+        upd = torch.empty(B, T, nt, **kw)
+        info = torch.empty(B, dtype=torch.int32, device=dev)
+        x_est = xi
+        merit = meritfn(x_est, Q, q, lam, x0, rho)
+        status = None
+        failed = False
+        for _ in range(MAX_NEWTON_STEPS):
+            xu = d64(x_est)
+            with torch.enable_grad():       # autograd-based dx_jac callables need leaves (al_utils.py:409-411)
+                xs = xu[:, :-1, :n].reshape(-1, n).to(xi.dtype).requires_grad_(True)
+                us = xu[:, :-1, n:].reshape(-1, m).to(xi.dtype).requires_grad_(True)
+                x_next, (Jx, Ju) = dx_jac(xs, us)
+            hold = [d64(x_next), d64(Jx), d64(Ju)]
+            with torch.cuda.device(dev):
+                rc = lib.dqp_al_banded_newton_step_jac(ctypes.byref(dims), _ptr(xu), _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]),
+                                                       _ptr(keep[3]), _ptr(keep[4]), _ptr(keep[5]), _ptr(keep[6]),
+                                                       _ptr(hold[0]), _ptr(hold[1]), _ptr(hold[2]), _ptr(upd), _ptr(fac),
+                                                       _ptr(info), _stream(dev))
+            _lib.check(rc, "dqp_al_banded_newton_step_jac")
+            if bool((info != 0).any()):     # a pivot was not positive: the reference switches to an LU solve
+                failed = True               # (al_utils.py:419-427); here the caller re-runs the dense path
+                break
+            update = upd.to(x_est.dtype)
+            if ls:
+                x_est, merit, _, status = line_search_newton(
+                    update, x_est, lambda c: meritfn(c, Q, q, lam, x0, rho), merit, x0)
+            else:
+                x_est = x_est + update
+                merit = meritfn(x_est, Q, q, lam, x0, rho)
+        ctx.dims, ctx.failed = dims, failed
+        ctx.save_for_backward(fac, x_est)
+        if status is None:
+            status = torch.ones(B, device=dev)
+        return x_est, status, torch.tensor(failed, device=dev)
+
+    @staticmethod
+    def backward(ctx, x_grad, status_grad, failed_grad):
+        fac, x = ctx.saved_tensors
+        rhs = x_grad.detach().double().contiguous()
+        g = torch.empty_like(rhs)
+        with torch.cuda.device(rhs.device):
+            rc = _lib.load().dqp_al_banded_solve(ctypes.byref(ctx.dims), 0, _ptr(fac), _ptr(rhs), _ptr(g), _stream(rhs.device))
+        _lib.check(rc, "dqp_al_banded_solve")
+        g = g.to(x_grad.dtype)
+        # diagonal cost: dQ = g * x, dq = g                          al_utils.py:482-485
+        return (None,) * 6 + (g * x, g, None, None, None)
+
+
 class NewtonALDevice(torch.autograd.Function):
     """NewtonAL for a dynamics.DeviceDynamics: the four Newton steps as one C-ABI call
     (dqp_al_newton_solve: 21 launches, no host involvement); backward as NewtonAL's.  `slow` is a

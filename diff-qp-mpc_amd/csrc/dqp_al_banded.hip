@@ -39,12 +39,21 @@ using dqp::dyn::Dual;
 struct BandP {
     const double *xu, *x0, *Qd, *q, *lam, *rho, *ul, *uu;    // forward inputs
     const double *rhs;                                       // solve-only mode: right-hand side (B, nz)
+    const double *xnext, *Jx, *Ju;                           // caller-supplied linearisation (Given<>): f(x_t,u_t) (B,T-1,n),
+                                                             // df/dx (B,T-1,n,n), df/du (B,T-1,n,m)
     double *upd;        // (B, T, nt): -H^-1 grad  (or -H^-1 rhs in solve-only mode)
     double *fac;        // banded factor, per (b, t): nt rows x (nt + 1 + nx) doubles
     int32_t *info;      // (B): 0 or 1 + knot of the first non-positive pivot
     double dt;
     int B, T;
 };
+
+// A dynamics the caller linearised itself (a torch module with its own Jacobians, deqmpc/envs.py:50-82,
+// rex_quadrotor.py:131-146): sizes only; the kernel reads f, df/dx, df/du from memory instead of evaluating a
+// registered model with forward-mode seeds.
+template <int NX_, int NU_> struct Given { static constexpr int NX = NX_, NU = NU_; };
+template <class M> struct is_given { static constexpr bool value = false; };
+template <int A, int B_> struct is_given<Given<A, B_>> { static constexpr bool value = true; };
 
 template <class Map> struct BandCfg {
     static constexpr int NX = Map::NX, NU = Map::NU, NT = NX + NU;
@@ -95,7 +104,19 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
         for (int j = 0; j < NX; ++j) xn1[j] = dynrow ? xu[(t + 1) * NT + j] : 0.0;
         // ---- column r of J_t = [df/dx df/du] by one forward-mode seed per lane
         double Jc[NX], mu[NX];
-        {
+        if constexpr (is_given<Map>::value) {
+            const int tc = dynrow ? t : 0;
+            const double *fx = P.xnext + (b * (long long)(T - 1) + tc) * NX;
+            const double *jx = P.Jx + (b * (long long)(T - 1) + tc) * NX * NX;
+            const double *ju = P.Ju + (b * (long long)(T - 1) + tc) * NX * NU;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                const double col = r < NX ? jx[j * NX + r] : ju[j * NU + (inT ? r - NX : 0)];
+                Jc[j] = (dynrow && inT) ? col : 0.0;
+                const double res = dynrow ? xn1[j] - fx[j] : 0.0;
+                mu[j] = dynrow ? lam[t * NX + j] + rho * res : 0.0;
+            }
+        } else {
             Dual<1> xs[NX], us[NU], out[NX];
 #pragma unroll
             for (int j = 0; j < NX; ++j) { xs[j] = Dual<1>(z[j]); xs[j].d[0] = (r == j) ? 1.0 : 0.0; }
@@ -281,10 +302,22 @@ template <class Map> int run_solve(const BandP &P, void *stream)
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
-int knot_doubles(int id)          // nt rows x (L row, 1/diag, M row)
+// (n_state, n_ctrl) pairs with a caller-linearised instantiation
+#define DQP_BAND_SIZES X(12, 4) X(3, 3) X(3, 1) X(4, 1) X(6, 1) X(2, 1) X(4, 2) X(3, 2) X(6, 2) X(8, 2)
+
+bool given_supported(int n, int m)
 {
-    int32_t n = 0, m = 0;
-    if (dqp_dyn_sizes(id, &n, &m) != DQP_OK) return 0;
+#define X(a, b) if (n == a && m == b) return true;
+    DQP_BAND_SIZES
+#undef X
+    return false;
+}
+
+int knot_doubles(int id, int n_, int m_)          // nt rows x (L row, 1/diag, M row)
+{
+    int32_t n = n_, m = m_;
+    if (id != 0 && dqp_dyn_sizes(id, &n, &m) != DQP_OK) return 0;
+    if (id == 0 && !given_supported(n, m)) return 0;
     return (n + m) * ((n + m) + 1 + n);
 }
 
@@ -296,7 +329,7 @@ extern "C" {
 
 __attribute__((visibility("default"))) size_t dqp_al_banded_factor_bytes(const dqp_al_mpc_dims *d, int dyn_id)
 {
-    const int kd = knot_doubles(dyn_id);
+    const int kd = d ? knot_doubles(dyn_id, d->n_state, d->n_ctrl) : 0;
     if (!d || d->nbatch <= 0 || d->T < 2 || kd == 0) return 0;
     return (size_t)d->nbatch * d->T * kd * sizeof(double);
 }
@@ -312,7 +345,8 @@ dqp_al_banded_newton_step(const dqp_al_mpc_dims *d, int dyn_id, double dt, const
     if (dqp_dyn_sizes(dyn_id, &n, &m) != DQP_OK || n != d->n_state || m != d->n_ctrl) return DQP_ERR_BAD_ARG;
     if (d->nbatch == 0) return DQP_OK;
     if (!xu || !x0 || !Qdiag || !q || !lam || !rho || !u_lower || !u_upper || !update || !factor) return DQP_ERR_BAD_ARG;
-    BandP P = {xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, nullptr, update, (double *)factor, info, dt, d->nbatch, d->T};
+    BandP P = {xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, nullptr, nullptr, nullptr, nullptr, update, (double *)factor,
+               info, dt, d->nbatch, d->T};
     switch (dyn_id) {
     case DQP_DYN_PENDULUM1L: return run_newton<Robot<Pendulum1l>>(P, stream);
     case DQP_DYN_CARTPOLE1L: return run_newton<Robot<Cartpole1l>>(P, stream);
@@ -329,11 +363,17 @@ dqp_al_banded_solve(const dqp_al_mpc_dims *d, int dyn_id, const void *factor, co
 {
     if (!d || d->nbatch < 0 || d->T < 2) return DQP_ERR_BAD_ARG;
     int32_t n = 0, m = 0;
-    if (dqp_dyn_sizes(dyn_id, &n, &m) != DQP_OK || n != d->n_state || m != d->n_ctrl) return DQP_ERR_BAD_ARG;
+    if (dyn_id != 0 && (dqp_dyn_sizes(dyn_id, &n, &m) != DQP_OK || n != d->n_state || m != d->n_ctrl)) return DQP_ERR_BAD_ARG;
     if (d->nbatch == 0) return DQP_OK;
     if (!factor || !rhs || !out) return DQP_ERR_BAD_ARG;
     BandP P = {};
     P.rhs = rhs; P.upd = out; P.fac = (double *)factor; P.B = d->nbatch; P.T = d->T;
+    if (dyn_id == 0) {          // the factor of dqp_al_banded_newton_step_jac: layout by sizes
+#define X(a, b) if (d->n_state == a && d->n_ctrl == b) return run_solve<Given<a, b>>(P, stream);
+        DQP_BAND_SIZES
+#undef X
+        return DQP_ERR_TOO_LARGE;
+    }
     switch (dyn_id) {
     case DQP_DYN_PENDULUM1L: return run_solve<Robot<Pendulum1l>>(P, stream);
     case DQP_DYN_CARTPOLE1L: return run_solve<Robot<Cartpole1l>>(P, stream);
@@ -342,6 +382,28 @@ dqp_al_banded_solve(const dqp_al_mpc_dims *d, int dyn_id, const void *factor, co
     case DQP_DYN_REXQUADROTOR: return run_solve<RexQuadrotor>(P, stream);
     default: return run_solve<PendulumDx>(P, stream);
     }
+}
+
+/*
+ * The same block-tridiagonal Newton step for a dynamics the CALLER linearised (include/dqp.h).
+ */
+__attribute__((visibility("default"))) int
+dqp_al_banded_newton_step_jac(const dqp_al_mpc_dims *d, const double *xu, const double *x0, const double *Qdiag,
+                              const double *q, const double *lam, const double *rho, const double *u_lower,
+                              const double *u_upper, const double *x_next, const double *Jx, const double *Ju,
+                              double *update, void *factor, int32_t *info, void *stream)
+{
+    if (!d || d->nbatch < 0 || d->T < 2 || d->n_state < 1 || d->n_ctrl < 1) return DQP_ERR_BAD_ARG;
+    if (!given_supported(d->n_state, d->n_ctrl)) return DQP_ERR_TOO_LARGE;
+    if (d->nbatch == 0) return DQP_OK;
+    if (!xu || !x0 || !Qdiag || !q || !lam || !rho || !u_lower || !u_upper || !x_next || !Jx || !Ju || !update || !factor)
+        return DQP_ERR_BAD_ARG;
+    BandP P = {xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, nullptr, x_next, Jx, Ju, update, (double *)factor, info, 0.0,
+               d->nbatch, d->T};
+#define X(a, b) if (d->n_state == a && d->n_ctrl == b) return run_newton<Given<a, b>>(P, stream);
+    DQP_BAND_SIZES
+#undef X
+    return DQP_ERR_TOO_LARGE;
 }
 
 }  // extern "C"

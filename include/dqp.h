@@ -403,6 +403,20 @@ int dqp_al_banded_newton_step(const dqp_al_mpc_dims *dims, int dyn_id, double dt
                               double *update, void *factor, int32_t *info, void *stream);
 int dqp_al_banded_solve(const dqp_al_mpc_dims *dims, int dyn_id, const void *factor, const double *rhs,
                         double *out, void *stream);
+/*
+ * The same step for a dynamics the CALLER linearised -- a torch module with its own Jacobians such as
+ * deqmpc/envs.py:50-82 or RexQuadrotor_dynamics_jac (rex_quadrotor.py:131-146) -- at any horizon:
+ * x_next (B,T-1,n) = f(x_t,u_t), Jx (B,T-1,n,n) = df/dx, Ju (B,T-1,n,m) = df/du instead of a registered
+ * model.  Lifts the nz <= 128 limit of dqp_al_newton_step for user dynamics (config 4 with the reference's
+ * own quadrotor module: nz = 480).  Compiled (n_state, n_ctrl) pairs: DQP_BAND_SIZES in csrc/dqp_al_banded.hip;
+ * others return DQP_ERR_TOO_LARGE.  The factor has the layout of dqp_al_banded_factor_bytes(dims, 0) and is
+ * applied by dqp_al_banded_solve(dims, 0, ...).
+ */
+int dqp_al_banded_newton_step_jac(const dqp_al_mpc_dims *dims, const double *xu, const double *x0,
+                                  const double *Qdiag, const double *q, const double *lam, const double *rho,
+                                  const double *u_lower, const double *u_upper, const double *x_next,
+                                  const double *Jx, const double *Ju, double *update, void *factor,
+                                  int32_t *info, void *stream);
 
 /* ----------------------------------------------------------------- device dynamics registry */
 

@@ -445,3 +445,57 @@ def test_reference_entry_points_of_the_jacobian_fill():
     Hm = al_utils.merit_hessian(xu, Qd, None, dyn.jac, x0, None, rho, None, None, lo, hi)
     want = np.stack([np.diag(Qd[b].reshape(-1).cpu().numpy()) + float(rho[b]) * Jc0[b].T @ Jc0[b] for b in range(B)])
     np.testing.assert_allclose(Hm.cpu().numpy(), want, atol=1e-10)
+
+
+class _UserModule(torch.nn.Module):
+    """A dynamics the solver knows nothing about (a plain callable with its own Jacobian function), as a
+    caller's torch module would be; the arithmetic is borrowed from the registry so that the reference
+    fixtures apply."""
+
+    def __init__(self, name, dt):
+        super().__init__()
+        from diff_qp_mpc_amd.dynamics import DeviceDynamics
+        self._d = DeviceDynamics(name, dt=dt)
+
+    def forward(self, x, u):
+        return self._d(x, u)
+
+    def jac(self, x, u):
+        return self._d.jac(x, u)
+
+
+@pytest.mark.parametrize("name,robot", [("CFG4_rexquadrotor_T30_b4", "rexquadrotor"), ("CFG4_rexquadrotor_T6_b4", "rexquadrotor"),
+                                        ("CFG3_cartpole1l_T20_b4", "cartpole1l")])
+def test_al_mpc_user_dynamics_module_banded(name, robot):
+    """AL_mpc.MPC with a caller-supplied dynamics module (not a DeviceDynamics): from nz > 128 on its own
+    Jacobians go to dqp_al_banded_newton_step_jac (config 4: nz = 480, beyond the dense Newton step).  Against
+    the reference's AL_mpc.MPC fixtures (cold call, gradients, warm-started call); the cartpole case (nz = 100)
+    forces the banded path below the threshold and must agree with the same fixtures too."""
+    from diff_qp_mpc_amd import AL_mpc, al_utils
+    g = load(name)
+    B, T = g["in_Qd"].shape[:2]
+    dyn = _UserModule(robot, float(g["dt"])).cuda()
+    nx, nu = dyn._d.n_state, dyn._d.n_ctrl
+    old = AL_mpc.BANDED_USER_DYNAMICS_FROM_NZ
+    AL_mpc.BANDED_USER_DYNAMICS_FROM_NZ = 0
+    try:
+        x0 = dev(g["in_x0"])
+        C = torch.diag_embed(dev(g["in_Qd"])).requires_grad_()
+        c = dev(g["in_c"], grad=True)
+        ctrl = AL_mpc.MPC(nx, nu, T, u_lower=dev(g["in_u_lower"]), u_upper=dev(g["in_u_upper"]), n_batch=B,
+                          verbose=0, solver_type="dense", dtype=torch.float64, eps=1e-5,
+                          exit_unconverged=False, backprop=False)
+        ctrl.reinitialize(x0, torch.ones(B, T, 1, device="cuda"))
+        ctrl.x_init, ctrl.u_init = dev(g["in_x_init"]), dev(g["in_u_init"])
+        x, u = ctrl(x0, al_utils.QuadCost(C, c), dyn, dyn.jac)
+        np.testing.assert_allclose(x.detach().cpu().numpy(), g["x1"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(u.detach().cpu().numpy(), g["u1"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(ctrl.lamda_prev.cpu().numpy(), g["lam1"], rtol=1e-5, atol=1e-5)
+        (x.double().sum() + 2.0 * u.double().sum()).backward()
+        np.testing.assert_allclose(C.grad.diagonal(dim1=-2, dim2=-1).cpu().numpy(), g["dC1"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(c.grad.cpu().numpy(), g["dc1"], rtol=1e-4, atol=1e-5)
+        x2, u2 = ctrl(x0, al_utils.QuadCost(C.detach(), c.detach()), dyn, dyn.jac)
+        np.testing.assert_allclose(x2.cpu().numpy(), g["x2"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(u2.cpu().numpy(), g["u2"], rtol=1e-4, atol=1e-4)
+    finally:
+        AL_mpc.BANDED_USER_DYNAMICS_FROM_NZ = old
