@@ -303,7 +303,9 @@ template <class Map> int run_solve(const BandP &P, void *stream)
 }
 
 // (n_state, n_ctrl) pairs with a caller-linearised instantiation
-#define DQP_BAND_SIZES X(12, 4) X(3, 3) X(3, 1) X(4, 1) X(6, 1) X(2, 1) X(4, 2) X(3, 2) X(6, 2) X(8, 2)
+#define DQP_BAND_SIZES                                                                                   \
+    X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(6, 1) X(7, 1) X(8, 1) X(2, 2) X(3, 2) X(4, 2) X(5, 2) X(6, 2) X(8, 2) \
+    X(10, 2) X(12, 2) X(3, 3) X(6, 3) X(9, 3) X(4, 4) X(6, 4) X(8, 4) X(10, 4) X(12, 4)
 
 bool given_supported(int n, int m)
 {

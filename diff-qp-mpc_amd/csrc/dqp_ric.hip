@@ -762,7 +762,9 @@ template <class C, class Kern> int launch(Kern kernel, const KParams &P, int T, 
 }  // namespace ric
 
 // size table: (n_state, n_ctrl) pairs with a stage-wise kernel
-#define DQP_RIC_SIZES X(12, 4) X(3, 3) X(3, 1) X(4, 1) X(6, 1) X(2, 1) X(4, 2)
+#define DQP_RIC_SIZES                                                                                   \
+    X(12, 4) X(3, 3) X(3, 1) X(4, 1) X(6, 1) X(2, 1) X(4, 2) X(5, 1) X(8, 1) X(2, 2) X(3, 2) X(6, 2) X(8, 2) X(6, 3)  \
+    X(4, 4) X(8, 4) X(10, 4) X(12, 2)
 
 bool ric_supported(int n, int m)
 {

@@ -326,3 +326,17 @@ def test_riccati_kkt_solve_against_a_dense_solve():
     np.testing.assert_allclose(dc.cpu().numpy().transpose(1, 0, 2).reshape(B, -1), dx_ref, rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(df.cpu().numpy().transpose(1, 0, 2).reshape(B, -1), dy_ref[:, :(T - 1) * n], rtol=1e-8, atol=1e-10)
     np.testing.assert_allclose(dx0.cpu().numpy(), -dy_ref[:, (T - 1) * n:], rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("n,m,T,B", [(5, 1, 6, 7), (8, 2, 5, 5), (6, 3, 4, 6), (10, 4, 3, 4), (2, 2, 5, 9)])
+def test_stagewise_more_size_pairs(n, m, T, B):
+    """Other compiled (n_state, n_ctrl) pairs of the stage-wise kernels against the CPU oracle."""
+    data = problem(n, m, T, B, seed=5 * n + m + T)
+    tau, grads, w = run_fused(n, m, T, data)
+    Q, p, G, h, A, b = assemble(*data)
+    o = oracle.dense_forward(Q, p, G, h, A, b)
+    np.testing.assert_allclose(tau.reshape(B, -1), o["zhat"], **ZT)
+    og = oracle.dense_backward(o["K"], o["zhat"], o["lam"], o["nu"], w.reshape(B, -1))
+    nt = n + m
+    dc = np.stack([og["dp"][:, t * nt:(t + 1) * nt] for t in range(T)])
+    np.testing.assert_allclose(grads[1], dc, err_msg="dc", **GT)
