@@ -297,7 +297,8 @@ def main():
                          "note": "fp64-issue bound, not HBM bound (DESIGN.md §4): every wavefront runs max_iter "
                                  "iterations at ~4.7 cycles per VALU instruction; measured traffic = algorithmic "
                                  "inputs/outputs + the factorisation context written for backward (which then "
-                                 "reads it instead of Q, G, A)"},
+                                 "reads it instead of Q, G, A) + the improving iterates and residual history the "
+                                 "batch rule's finish pass reads"},
             "kernels": {"forward_call_ms": fwd_ms, "forward_pass1_kernel_ms": pass1_ms,
                         "qp_backward_kernel_ms": bwd_ms,
                         "backward_GBps": bwd_bytes / (bwd_ms * 1e-3) / 1e9,
