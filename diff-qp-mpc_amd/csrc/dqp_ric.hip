@@ -80,11 +80,117 @@ template <class C> struct Ctx {
     bool xl, ul, live;              // lane holds a state row / a control row / a real problem
     int a;                          // control index of a control lane (0 otherwise)
     double uu, ulo;                 // bounds of this lane's control
-    // the inputs never alias the workspace: restrict-qualified so that their loads may be hoisted above
-    // the workspace stores of the previous knot
-    __device__ const double *__restrict__ Crow(int t) const { return P.mC + (((long long)t * P.B + qp) * C::NT + (r < C::NT ? r : 0)) * C::NT; }
-    __device__ const double *__restrict__ Frow(int t) const { return P.mF + (((long long)t * P.B + qp) * C::NX + (xl ? r : 0)) * C::NT; }
-    __device__ const double *__restrict__ Fmat(int t) const { return P.mF + ((long long)t * P.B + qp) * C::NX * C::NT; }
+    int lane, g, qmax;              // lane, place of its problem in the wavefront, last place with a problem of its own
+    long long qp0;                  // problem at place 0
+    double *w0;                     // workspace of place 0 (places are L.total doubles apart)
+    double *img;                    // the wavefront's LDS stage (Stage<C>)
+    // knot t of the wavefront's four problems: contiguous in the (T, B, ., .) inputs
+    __device__ const double *Cblk(int t) const { return P.mC + ((long long)t * P.B + qp0) * (C::NT * C::NT); }
+    __device__ const double *Fblk(int t) const { return P.mF + ((long long)t * P.B + qp0) * (C::NX * C::NT); }
+    __device__ const double *FACblk(int t) const { return w0 + L.FAC + (long long)t * (C::NT * C::NT); }
+};
+
+// A copy of the context whose per-lane address roots the compiler must treat as new values: every
+// sweep is inlined into the iteration loop, and without this LICM hoists the address arithmetic of all
+// of them (array bases, DMA source offsets, swizzled LDS addresses: ~150 registers) out of that loop and
+// spills it; the reloads then sit in every knot.
+template <class C> __device__ __forceinline__ Ctx<C> fresh(const Ctx<C> &K0)
+{
+    Ctx<C> K = K0;
+    asm volatile("" : "+v"(K.r), "+v"(K.lane), "+v"(K.g), "+v"(K.w));
+    K.xl = K.r < C::NX;
+    K.ul = K.r >= C::NX && K.r < C::NT;
+    K.a = K.ul ? K.r - C::NX : 0;
+    return K;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS stage.  A sweep visits the knots one after the other and every knot is a chain
+// "load its matrices -> a few hundred FMAs -> store": with the loads issued at the knot itself a
+// wavefront waits out several memory round trips per knot (12 us per knot at config 4, measured).
+// The matrices of knot t -+ 1 are therefore fetched while knot t computes, by LDS-DMA
+// (global_load_lds: no destination registers, the kernel has none to spare) into one image per
+// wavefront; the per-knot vectors are prefetched through registers.  An image holds the knot's
+// NT x NT matrix (C_t, or the factor rows of the knot) and its NX x NT matrix F_t for the four problems.
+// The DMA writes LDS lane-linearly (wave base + lane * PIECE), so the XOR swizzle that keeps the
+// 16-lane row reads off a single bank group is applied to the SOURCE address of each piece.
+typedef __attribute__((address_space(1))) const void gvoid_t;
+typedef __attribute__((address_space(3))) void lvoid_t;
+
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <class C> struct Stage {
+    static constexpr int NX = C::NX, NT = C::NT;
+    static constexpr int PIECE = (NT % 2 == 0) ? 16 : 4;            // bytes per lane of one DMA instruction
+    static constexpr int PPR = NT * 8 / PIECE;                       // pieces per matrix row
+    // rows of 2^k 16-byte pieces start on few distinct bank groups: piece j of row `row` sits at j ^ swz(row)
+    static constexpr int SWZ_DIV = (PIECE == 16 && PPR > 1 && PPR <= 8 && (PPR & (PPR - 1)) == 0) ? 16 / PPR : 0;
+    static constexpr int pad64(int pieces) { return (pieces + 63) / 64 * 64; }
+    static constexpr int MAT = pad64(4 * NT * PPR) * PIECE / 8;      // doubles
+    static constexpr int FMT = pad64(4 * NX * PPR) * PIECE / 8;
+    static constexpr int TOTAL = MAT + FMT;
+    __device__ __forceinline__ static int swz(int row) { return SWZ_DIV ? (row / (SWZ_DIV ? SWZ_DIV : 1)) & (PPR - 1) : 0; }
+    // element (row, c) of place g in an image of ROWS-row matrices
+    template <int ROWS> __device__ __forceinline__ static int at(int g, int row, int c)
+    {
+        if constexpr (PIECE == 16) return (g * ROWS + row) * NT + ((((c >> 1) ^ swz(row)) << 1) | (c & 1));
+        else return (g * ROWS + row) * NT + c;
+    }
+    // columns [C0, C1) of row `row` of place g.  With the swizzle, piece j of the row is at index
+    // (base | s << 1) ^ (j << 1) (base is a multiple of the row length 2 PPR, a power of two there): one
+    // XOR per piece off a single register, which is handed to the compiler as a new value at every call --
+    // kept as loop invariants the piece addresses of a kernel's sweeps are ~60 registers, spilled and
+    // reloaded one by one in front of the reads.
+    template <int ROWS, int C0, int C1, int N>
+    __device__ __forceinline__ static void cols(const double *img, int g, int row, double (&out)[N])
+    {
+        static_assert(N == C1 - C0, "");
+        if constexpr (PIECE == 16) {
+            int root = ((g * ROWS + row) * NT) | (swz(row) << 1);
+            asm volatile("" : "+v"(root));
+#pragma unroll
+            for (int j = C0 / 2; j <= (C1 - 1) / 2; ++j) {
+                const double2 v = *reinterpret_cast<const double2 *>(img + (SWZ_DIV ? (root ^ (j << 1)) : root + (j << 1)));
+                if (2 * j >= C0 && 2 * j < C1) out[2 * j - C0] = v.x;
+                if (2 * j + 1 >= C0 && 2 * j + 1 < C1) out[2 * j + 1 - C0] = v.y;
+            }
+        } else {
+            int root = (g * ROWS + row) * NT;
+            asm volatile("" : "+v"(root));
+#pragma unroll
+            for (int c = C0; c < C1; ++c) out[c - C0] = img[root + c];
+        }
+    }
+    // column `col` (rows 0 .. ROWS-1) of place g
+    template <int ROWS>
+    __device__ __forceinline__ static void column(const double *img, int g, int col, double (&out)[ROWS])
+    {
+        int root = g * ROWS * NT + col;
+        asm volatile("" : "+v"(root));
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+            if constexpr (PIECE == 16 && SWZ_DIV != 0) out[i] = img[(root ^ (((i / SWZ_DIV) & (PPR - 1)) << 1)) + i * NT];
+            else out[i] = img[root + i * NT];
+        }
+    }
+    // issue the DMA of one knot's ROWS x NT matrices: place q's matrix is at base + min(q, qmax) * qstride_bytes
+    template <int ROWS>
+    __device__ __forceinline__ static void fetch(double *img, const double *base, int qstride_bytes, int qmax, int lane)
+    {
+        constexpr int PIECES = 4 * ROWS * PPR, KN = (PIECES + 63) / 64;
+#pragma unroll
+        for (int k = 0; k < KN; ++k) {
+            int p = k * 64 + lane;
+            if constexpr (PIECES % 64 != 0) p = p < PIECES ? p : PIECES - 1;     // tail lanes refill the padding
+            const int rowg = p / PPR, j = p % PPR, q = rowg / ROWS, row = rowg % ROWS;
+            const int off = (q < qmax ? q : qmax) * qstride_bytes + (row * PPR + (j ^ swz(row))) * PIECE;
+            gvoid_t *src = (gvoid_t *)(reinterpret_cast<const char *>(base) + off);
+            lvoid_t *dst = (lvoid_t *)(img + k * (64 * PIECE / 8));
+            if constexpr (PIECE == 16) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
+        }
+    }
 };
 
 // y[r] = sum_c row[c] * v[c]  (row = this lane's matrix row, v distributed)
@@ -96,12 +202,68 @@ template <int N> __device__ __forceinline__ double mv_row(const double (&row)[N]
     return acc;
 }
 
+// H += F' (P F) for this lane's row of H: Pn = this lane's row of P_{t+1} (state lanes, zero elsewhere),
+// frow = its row of F_t (state lanes), fcol = its column of F_t
+template <class C>
+__device__ __forceinline__ void add_FtPF(double (&H)[C::NT], const double (&Pn)[C::NX], const double (&frow)[C::NT],
+                                         const double (&fcol)[C::NX])
+{
+    constexpr int NX = C::NX, NT = C::NT;
+    double PF[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {                  // PF = P_{t+1} F_t, row-distributed over the state lanes
+        double acc = 0.0;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) acc = fma(Pn[c], rb(frow[j], c), acc);
+        PF[j] = acc;
+    }
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        double acc = H[b];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) acc = fma(fcol[i], rb(PF[b], i), acc);
+        H[b] = acc;
+    }
+}
+
+// this lane's row of the knot's NT x NT matrix, its row and its column of F_t, out of the stage
+template <class C>
+__device__ __forceinline__ void stage_rows(const Ctx<C> &K, bool withF, double (&H)[C::NT], double (&frow)[C::NT],
+                                           double (&fcol)[C::NX])
+{
+    using S = Stage<C>;
+    constexpr int NX = C::NX, NT = C::NT;
+    const int r = K.r;
+    S::template cols<NT, 0, NT>(K.img, K.g, r < NT ? r : 0, H);
+    if (withF) {
+        S::template cols<NX, 0, NT>(K.img + S::MAT, K.g, K.xl ? r : 0, frow);
+        S::template column<NX>(K.img + S::MAT, K.g, r < NT ? r : 0, fcol);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) frow[c] = K.xl ? frow[c] : 0.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) fcol[i] = r < NT ? fcol[i] : 0.0;
+    }
+}
+template <class C> __device__ __forceinline__ void fetch_CF(const Ctx<C> &K, int t)
+{
+    using S = Stage<C>;
+    S::template fetch<C::NT>(K.img, K.Cblk(t), C::NT * C::NT * 8, K.qmax, K.lane);
+    if (t < K.T - 1) S::template fetch<C::NX>(K.img + S::MAT, K.Fblk(t), C::NX * C::NT * 8, K.qmax, K.lane);
+}
+template <class C> __device__ __forceinline__ void fetch_facF(const Ctx<C> &K, int t)
+{
+    using S = Stage<C>;
+    S::template fetch<C::NT>(K.img, K.FACblk(t), K.L.total * 8, 3, K.lane);
+    if (t < K.T - 1) S::template fetch<C::NX>(K.img + S::MAT, K.Fblk(t), C::NX * C::NT * 8, K.qmax, K.lane);
+}
+
 // ---------------------------------------------------------------------------------------------
 // backward Riccati sweep on the matrices; d = z/s from the iterate (unit: d = 1, clampd: the
 // reference's backward clamps, qp.py:131-134).  Returns false if a control pivot is not positive.
 template <class C>
-__device__ __forceinline__ bool factor(const Ctx<C> &K, bool unit, bool clampd)
+__device__ __forceinline__ bool factor(const Ctx<C> &K0, bool unit, bool clampd)
 {
+    const Ctx<C> K = fresh<C>(K0);
     constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
     const int r = K.r, T = K.T;
     double *w = K.w;
@@ -110,44 +272,28 @@ __device__ __forceinline__ bool factor(const Ctx<C> &K, bool unit, bool clampd)
 #pragma unroll
     for (int c = 0; c < NX; ++c) Pn[c] = 0.0;
     bool ok = true;
-    for (int t = T - 1; t >= 0; --t) {
-        double H[NT];
-        const double *__restrict__ cp = K.Crow(t);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) H[c] = r < NT ? cp[c] : (r == c ? 1.0 : 0.0);
-        if (K.ul) {
+    auto load_d = [&](int t) {
+        double dd = 2.0;
+        if (K.ul && !unit) {
             const int iu = t * NU + K.a;
-            double dd = 2.0;
-            if (!unit) {
-                double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
-                if (clampd) { su = fmax(su, 1e-8); sl = fmax(sl, 1e-8); zu = fmax(zu, 1e-8); zl = fmax(zl, 1e-8); }
-                dd = zu / su + zl / sl;
-            }
-#pragma unroll
-            for (int c = 0; c < NT; ++c) H[c] += (r == c) ? dd : 0.0;
+            double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
+            if (clampd) { su = fmax(su, 1e-8); sl = fmax(sl, 1e-8); zu = fmax(zu, 1e-8); zl = fmax(zl, 1e-8); }
+            dd = zu / su + zl / sl;
         }
-        if (t < T - 1) {
-            double frow[NT], fcol[NX], PF[NT];
-            const double *__restrict__ fp = K.Frow(t), *__restrict__ fm = K.Fmat(t);
+        return dd;
+    };
+    double dd = load_d(T - 1);
+    fetch_CF<C>(K, T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+        double H[NT], frow[NT], fcol[NX];
+        wait_vm();
+        stage_rows<C>(K, t < T - 1, H, frow, fcol);
+        wait_lds();
+        double dn = dd;
+        if (t > 0) { dn = load_d(t - 1); fetch_CF<C>(K, t - 1); }
 #pragma unroll
-            for (int c = 0; c < NT; ++c) frow[c] = K.xl ? fp[c] : 0.0;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) fcol[i] = r < NT ? fm[i * NT + r] : 0.0;
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {                  // PF = P_{t+1} F_t, row-distributed over the state lanes
-                double acc = 0.0;
-#pragma unroll
-                for (int c = 0; c < NX; ++c) acc = fma(Pn[c], rb(frow[j], c), acc);
-                PF[j] = acc;
-            }
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {                  // H += F_t' (P F)
-                double acc = H[b];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) acc = fma(fcol[i], rb(PF[b], i), acc);
-                H[b] = acc;
-            }
-        }
+        for (int c = 0; c < NT; ++c) H[c] = r < NT ? H[c] + ((K.ul && r == c) ? dd : 0.0) : (r == c ? 1.0 : 0.0);
+        if (t < T - 1) add_FtPF<C>(H, Pn, frow, fcol);
         // partial Cholesky on the control pivots j = NX .. NT-1
         double rdj_keep = 0.0;
 #pragma unroll
@@ -172,6 +318,7 @@ __device__ __forceinline__ bool factor(const Ctx<C> &K, bool unit, bool clampd)
         }
 #pragma unroll
         for (int c = 0; c < NX; ++c) Pn[c] = K.xl ? H[c] : 0.0;
+        dd = dn;
     }
     return ok;
 }
@@ -209,15 +356,23 @@ __device__ __forceinline__ double model_next(int dyn_id, double tau, double dt, 
     }
 }
 
+template <class C, class Map> constexpr bool model_fits() { return Map::NX == C::NX && Map::NU == C::NU; }
+template <class C> constexpr bool has_model()
+{
+    using namespace dqp::dyn;
+    return model_fits<C, Robot<Pendulum1l>>() || model_fits<C, Robot<Cartpole1l>>() || model_fits<C, Robot<Cartpole2l>>() ||
+           model_fits<C, PendulumEuler>() || model_fits<C, PendulumDx>() || model_fits<C, RexQuadrotor>();
+}
+
 // ---------------------------------------------------------------------------------------------
 // One backward sweep for the three things an iteration needs from every knot before it can move:
 // the residuals of the iterate (batch.py:93-108: rx = C tau + c + G'z + A'y, rz = G tau + s - h,
 // ry = A tau - b), the Riccati factorisation with d = z/s (as factor()) and the affine right-hand side
-// pushed through it (as sweep_back<AFFINE>) -- C_t and F_t are read
-// once instead of three times (the kernel is bound by those streams).
-template <class C>
-__device__ __forceinline__ bool factor_fused(const Ctx<C> &K, double &nx2, double &nz2, double &ny2, double &sz)
+// pushed through it (as sweep_back<AFFINE>) -- C_t and F_t are read once instead of three times.
+template <class C, bool DYN>
+__device__ __forceinline__ bool factor_fused(const Ctx<C> &K0, double &nx2, double &nz2, double &ny2, double &sz)
 {
+    const Ctx<C> K = fresh<C>(K0);
     constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
     const int r = K.r, T = K.T;
     double *w = K.w;
@@ -228,18 +383,48 @@ __device__ __forceinline__ bool factor_fused(const Ctx<C> &K, double &nx2, doubl
     for (int c = 0; c < NX; ++c) Pn[c] = 0.0;
     double pn = 0.0;
     bool ok = true;
-    for (int t = T - 1; t >= 0; --t) {
-        // ---- loads
-        const double tau = r < NT ? w[L.X + t * NT + r] : 0.0;
-        double H[NT];
-        const double *__restrict__ cp = K.Crow(t);
+    // the knot's vectors: tau_t, c_t, (s, z)_t, y_{t-1} (t = 0: the multiplier of x_0 = x0), f_t, x0
+    enum { V_TAU, V_MC, V_SU, V_SL, V_ZU, V_ZL, V_YP, V_MF, V_X0, V_N };
+    auto load_vec = [&](const Ctx<C> &K, int t, double (&v)[V_N]) {
+        const int r = K.r;
+        double *w = K.w;
 #pragma unroll
-        for (int c = 0; c < NT; ++c) H[c] = r < NT ? cp[c] : 0.0;
-        double rx = mv_row<NT>(H, tau) + (r < NT ? K.P.mc[((long long)t * K.P.B + K.qp) * NT + r] : 0.0);
+        for (int i = 0; i < V_N; ++i) v[i] = (i == V_SU || i == V_SL) ? 1.0 : 0.0;
+        if (r < NT) { v[V_TAU] = w[L.X + t * NT + r]; v[V_MC] = K.P.mc[((long long)t * K.P.B + K.qp) * NT + r]; }
+        if (K.ul) {
+            const int iu = t * NU + K.a;
+            v[V_SU] = w[L.SU + iu]; v[V_SL] = w[L.SL + iu]; v[V_ZU] = w[L.ZU + iu]; v[V_ZL] = w[L.ZL + iu];
+        }
+        if (K.xl) {
+            v[V_YP] = w[L.Y + (t >= 1 ? t - 1 : T - 1) * NX + r];
+            if (!DYN && t < T - 1) v[V_MF] = K.P.mf[((long long)t * K.P.B + K.qp) * NX + r];
+            if (t == 0) v[V_X0] = K.P.mx0[K.qp * NX + r];
+        }
+    };
+    double cur[V_N], nxt[V_N];
+    load_vec(K, T - 1, cur);
+    fetch_CF<C>(K, T - 1);
+    double x_next = 0.0, y_t = 0.0;         // x_{t+1} and y_t on the state lanes, carried from knot t + 1
+    for (int t = T - 1; t >= 0; --t) {
+        double H[NT], frow[NT], fcol[NX];
+        wait_vm();
+        stage_rows<C>(K, t < T - 1, H, frow, fcol);
+        wait_lds();
+        if (t > 0) {
+            const Ctx<C> Kt = fresh<C>(K);          // the prefetch addresses are recomputed per knot, not kept
+            load_vec(Kt, t - 1, nxt);
+            fetch_CF<C>(Kt, t - 1);
+        }
+        double *w;                                    // same for the stores of this knot
+        { const Ctx<C> Ks = fresh<C>(K); w = Ks.w; }
+        const double tau = cur[V_TAU];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) H[c] = r < NT ? H[c] : 0.0;
+        double rx = mv_row<NT>(H, tau) + cur[V_MC];
         double q = 0.0, e = 0.0;
         if (K.ul) {
             const int iu = t * NU + K.a;
-            const double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
+            const double su = cur[V_SU], sl = cur[V_SL], zu = cur[V_ZU], zl = cur[V_ZL];
             rx += zu - zl;
             const double rzu = tau - K.uu + su, rzl = -tau + K.ulo + sl;
             w[L.RZU + iu] = rzu; w[L.RZL + iu] = rzl;
@@ -252,50 +437,28 @@ __device__ __forceinline__ bool factor_fused(const Ctx<C> &K, double &nx2, doubl
         }
 #pragma unroll
         for (int c = 0; c < NT; ++c) H[c] = r < NT ? H[c] : (r == c ? 1.0 : 0.0);
-        double fcol[NX];
         if (t < T - 1) {
-            double frow[NT];
-            const double *__restrict__ fp = K.Frow(t), *__restrict__ fm = K.Fmat(t);
-#pragma unroll
-            for (int c = 0; c < NT; ++c) frow[c] = K.xl ? fp[c] : 0.0;
-#pragma unroll
-            for (int i = 0; i < NX; ++i) fcol[i] = r < NT ? fm[i * NT + r] : 0.0;
-            const double yt = K.xl ? w[L.Y + t * NX + r] : 0.0;
             double acc = 0.0;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) acc = fma(fcol[i], rb(yt, i), acc);
+            for (int i = 0; i < NX; ++i) acc = fma(fcol[i], rb(y_t, i), acc);
             rx += acc;
             // ry_t: the linearised dynamics, or the registered model itself (the reference's dyn_res closure,
             // qp_wrapper.py:309,316 -> batch_LU.py:97)
-            const double fx = K.P.dynId ? model_next<C>(K.P.dynId, tau, K.P.dynDt, r)
-                                        : mv_row<NT>(frow, tau) + (K.xl ? K.P.mf[((long long)t * K.P.B + K.qp) * NX + r] : 0.0);
+            double fx;
+            if constexpr (DYN) fx = model_next<C>(K.P.dynId, tau, K.P.dynDt, r);
+            else fx = mv_row<NT>(frow, tau) + cur[V_MF];
             if (K.xl) {
-                e = fx - w[L.X + (t + 1) * NT + r];
+                e = fx - x_next;
                 w[L.RY + t * NX + r] = e;
                 ny2 = fma(e, e, ny2);
             }
-            // H += F' P_{t+1} F
-            double PF[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                double a2 = 0.0;
-#pragma unroll
-                for (int c = 0; c < NX; ++c) a2 = fma(Pn[c], rb(frow[j], c), a2);
-                PF[j] = a2;
-            }
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                double a2 = H[b];
-#pragma unroll
-                for (int i = 0; i < NX; ++i) a2 = fma(fcol[i], rb(PF[b], i), a2);
-                H[b] = a2;
-            }
+            add_FtPF<C>(H, Pn, frow, fcol);
         }
         if (K.xl) {
-            if (t >= 1) rx -= w[L.Y + (t - 1) * NX + r];
+            if (t >= 1) rx -= cur[V_YP];
             else {
-                rx += w[L.Y + (T - 1) * NX + r];
-                const double ry = tau - K.P.mx0[K.qp * NX + r];
+                rx += cur[V_YP];
+                const double ry = tau - cur[V_X0];
                 w[L.RY + (T - 1) * NX + r] = ry;
                 ny2 = fma(ry, ry, ny2);
             }
@@ -342,118 +505,188 @@ __device__ __forceinline__ bool factor_fused(const Ctx<C> &K, double &nx2, doubl
         pn = K.xl ? h : 0.0;
 #pragma unroll
         for (int c = 0; c < NX; ++c) Pn[c] = K.xl ? H[c] : 0.0;
+        x_next = K.xl ? tau : 0.0;
+        y_t = K.xl ? cur[V_YP] : 0.0;
+#pragma unroll
+        for (int i = 0; i < V_N; ++i) cur[i] = nxt[i];
     }
     return ok;
 }
 
-// right-hand side of one stage for the four uses of the solver: q_t[r] (= -rhs1) and e_t[r]
-template <class C, int MODE>
-__device__ __forceinline__ void stage_rhs(const Ctx<C> &K, int t, double musig, double &q, double &e)
+// Right-hand side of one knot for the four uses of the solver, in two steps so that the loads of knot
+// t -+ 1 can be issued while knot t computes: rhs_load (memory) and rhs_q / rhs_e (arithmetic).
+//   q_t[r] = -rhs1 of the eliminated system, e_t[r] = ry_t
+enum { R_A, R_B, R_C, R_D, R_E, R_F, R_G, R_H, R_N };
+template <class C, int MODE, bool NEED_Q, bool NEED_E>
+__device__ __forceinline__ void rhs_load(const Ctx<C> &K, int t, double (&v)[R_N])
 {
     constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
     const int r = K.r, T = K.T;
     const double *w = K.w;
     const Lay &L = K.L;
-    q = 0.0; e = 0.0;
+#pragma unroll
+    for (int i = 0; i < R_N; ++i) v[i] = (i == R_B || i == R_C) ? 1.0 : 0.0;
     if (MODE == INIT) {            // batch.py:60-74: rx = p, rs = 0, rz = -h, ry = -b with d = 1
-        if (r < NT) q = K.P.mc[((long long)t * K.P.B + K.qp) * NT + r];
-        if (K.ul) q -= K.uu + K.ulo;
-        if (K.xl && t < T - 1) e = K.P.mf[((long long)t * K.P.B + K.qp) * NX + r];
+        if (NEED_Q && r < NT) v[R_A] = K.P.mc[((long long)t * K.P.B + K.qp) * NT + r];
+        if (NEED_E && K.xl && t < T - 1) v[R_H] = K.P.mf[((long long)t * K.P.B + K.qp) * NX + r];
     } else if (MODE == AFFINE) {   // rx, rs = z, rz, ry of the iterate
-        if (r < NT) q = w[L.RX + t * NT + r];
-        if (K.ul) {
-            const int iu = t * NU + K.a;
-            const double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
-            q -= (zu - zu / su * w[L.RZU + iu]) - (zl - zl / sl * w[L.RZL + iu]);
+        if (NEED_Q) {
+            if (r < NT) v[R_A] = w[L.RX + t * NT + r];
+            if (K.ul) {
+                const int iu = t * NU + K.a;
+                v[R_B] = w[L.SU + iu]; v[R_C] = w[L.SL + iu]; v[R_D] = w[L.ZU + iu]; v[R_E] = w[L.ZL + iu];
+                v[R_F] = w[L.RZU + iu]; v[R_G] = w[L.RZL + iu];
+            }
         }
-        if (K.xl && t < T - 1) e = w[L.RY + t * NX + r];
+        if (NEED_E && K.xl && t < T - 1) v[R_H] = w[L.RY + t * NX + r];
     } else if (MODE == CORRECTOR) {   // rx = 0, rs = (-mu sig + ds_aff dz_aff) / s, rz = ry = 0
-        if (K.ul) {
+        if (NEED_Q && K.ul) {
             const int iu = t * NU + K.a;
-            const double rsu = (-musig + w[L.DSU + iu] * w[L.DZU + iu]) / w[L.SU + iu];
-            const double rsl = (-musig + w[L.DSL + iu] * w[L.DZL + iu]) / w[L.SL + iu];
-            q = -(rsu - rsl);
+            v[R_B] = w[L.SU + iu]; v[R_C] = w[L.SL + iu];
+            v[R_D] = w[L.DSU + iu]; v[R_E] = w[L.DZU + iu]; v[R_F] = w[L.DSL + iu]; v[R_G] = w[L.DZL + iu];
         }
     } else {                       // ADJOINT: rx = dl/dzhat (qp.py:136-141)
-        if (r < NT) q = K.P.gin[(K.qp * T + t) * NT + r];            // dl/dtau is (B, T, nt) like tau
+        if (NEED_Q && r < NT) v[R_A] = K.P.gin[(K.qp * T + t) * NT + r];            // dl/dtau is (B, T, nt) like tau
     }
+}
+template <class C, int MODE>
+__device__ __forceinline__ double rhs_q(const Ctx<C> &K, const double (&v)[R_N], double musig)
+{
+    if (MODE == INIT) return v[R_A] - (K.ul ? K.uu + K.ulo : 0.0);
+    if (MODE == AFFINE) return K.ul ? v[R_A] - ((v[R_D] - v[R_D] / v[R_B] * v[R_F]) - (v[R_E] - v[R_E] / v[R_C] * v[R_G])) : v[R_A];
+    if (MODE == CORRECTOR) return K.ul ? -((-musig + v[R_D] * v[R_E]) / v[R_B] - (-musig + v[R_F] * v[R_G]) / v[R_C]) : 0.0;
+    return v[R_A];
 }
 
 // backward vector sweep: p_t and Luu^-1 h_u per stage
 template <class C, int MODE>
-__device__ __forceinline__ void sweep_back(const Ctx<C> &K, double musig)
+__device__ __forceinline__ void sweep_back(const Ctx<C> &K0, double musig)
 {
+    const Ctx<C> K = fresh<C>(K0);
+    using S = Stage<C>;
     constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    constexpr bool USE_E = (MODE == INIT || MODE == AFFINE);
     const int r = K.r, T = K.T;
     double *w = K.w;
     const Lay &L = K.L;
-    const double *__restrict__ fac = w + L.FAC;        // read-only during the sweeps: loads may pass the stores
     double pn = 0.0;
-    for (int t = T - 1; t >= 0; --t) {
-        double q, e;
-        stage_rhs<C, MODE>(K, t, musig, q, e);
-        double h = q;
-        if (t < T - 1) {
-            const double *__restrict__ pr = fac + ((long long)(t + 1) * NT + (K.xl ? r : 0)) * NT;
-            double v = pn;
-            if (MODE == INIT || MODE == AFFINE) {
+    double Pn[NX];                  // this lane's row of P_{t+1} (only where e != 0)
 #pragma unroll
-                for (int c = 0; c < NX; ++c) v = fma(K.xl ? pr[c] : 0.0, rb(e, c), v);
+    for (int c = 0; c < NX; ++c) Pn[c] = 0.0;
+    double cur[R_N], nxt[R_N];
+    rhs_load<C, MODE, true, USE_E>(K, T - 1, cur);
+    fetch_facF<C>(K, T - 1);
+    for (int t = T - 1; t >= 0; --t) {
+        double fcol[NX], lcol[NU], prow[NX];
+        wait_vm();
+        const int rr = r < NT ? r : 0;
+        S::template cols<NT, NX, NT>(K.img, K.g, rr, lcol);
+        const double rd = K.ul ? K.img[S::template at<NT>(K.g, rr, 0)] : 0.0;
+        if (USE_E) S::template cols<NT, 0, NX>(K.img, K.g, K.xl ? r : 0, prow);
+        if (t < T - 1) {
+            S::template column<NX>(K.img + S::MAT, K.g, rr, fcol);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) fcol[i] = r < NT ? fcol[i] : 0.0;
+        }
+        wait_lds();
+        if (t > 0) { rhs_load<C, MODE, true, USE_E>(K, t - 1, nxt); fetch_facF<C>(K, t - 1); }
+        double h = rhs_q<C, MODE>(K, cur, musig);
+        if (t < T - 1) {
+            double v = pn;
+            if (USE_E) {
+                const double e = cur[R_H];
+#pragma unroll
+                for (int c = 0; c < NX; ++c) v = fma(Pn[c], rb(e, c), v);
             }
-            const double *__restrict__ fm = K.Fmat(t);
             double acc = 0.0;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) acc = fma(r < NT ? fm[i * NT + r] : 0.0, rb(v, i), acc);
+            for (int i = 0; i < NX; ++i) acc = fma(fcol[i], rb(v, i), acc);
             h += acc;
         }
-        const double *__restrict__ lr = fac + ((long long)t * NT + (r < NT ? r : 0)) * NT;
-        const double rd = K.ul ? lr[0] : 0.0;
 #pragma unroll
         for (int j = NX; j < NT; ++j) {
             const double hj = rb(h, j) * rb(rd, j);
-            const double lij = (r < NT && (r < NX || r > j)) ? lr[j] : 0.0;
+            const double lij = (r < NT && (r < NX || r > j)) ? lcol[j - NX] : 0.0;
             h = (r == j) ? hj : fma(-lij, hj, h);
         }
         if (K.xl) w[L.PV + t * NX + r] = h;
         if (K.ul) w[L.YB + t * NU + K.a] = h;
         pn = K.xl ? h : 0.0;
+        if (USE_E) {
+#pragma unroll
+            for (int c = 0; c < NX; ++c) Pn[c] = K.xl ? prow[c] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < R_N; ++i) cur[i] = nxt[i];
     }
 }
 
 // forward sweep: dtau, dy, ds, dz of the solve; returns the lane-local minimum step ratio of
 // (s, z) against the direction that ends up in D* (affine: this solve; corrector: affine + this)
 template <class C, int MODE>
-__device__ __forceinline__ double sweep_fwd(const Ctx<C> &K, double musig)
+__device__ __forceinline__ double sweep_fwd(const Ctx<C> &K0, double musig)
 {
+    const Ctx<C> K = fresh<C>(K0);
+    using S = Stage<C>;
     constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    constexpr bool USE_E = (MODE == INIT || MODE == AFFINE);
     const int r = K.r, T = K.T;
     double *w = K.w;
     const Lay &L = K.L;
-    const double *__restrict__ fac = w + L.FAC, *__restrict__ pvv = w + L.PV, *__restrict__ ybv = w + L.YB;
     double ratio = INFINITY;
+    // the knot's vectors: p_t, Luu^-1 h_u, e_t, the constraint rows of the knot's control, and in the
+    // corrector the affine step they are added to
+    enum { V_PV, V_YB, V_E, V_SU, V_SL, V_ZU, V_ZL, V_A, V_B, V_C, V_D, V_DXO, V_DYO, V_N };
+    auto load_vec = [&](int t, double (&v)[V_N]) {
+#pragma unroll
+        for (int i = 0; i < V_N; ++i) v[i] = (i == V_SU || i == V_SL) ? 1.0 : 0.0;
+        if (K.xl) {
+            v[V_PV] = w[L.PV + t * NX + r];
+            if (USE_E) {
+                double rh[R_N];
+                rhs_load<C, MODE, false, true>(K, t, rh);
+                v[V_E] = rh[R_H];
+            }
+            if (MODE == CORRECTOR) v[V_DYO] = w[L.DY + (t >= 1 ? t - 1 : T - 1) * NX + r];
+        }
+        if (MODE == CORRECTOR && r < NT) v[V_DXO] = w[L.DX + t * NT + r];
+        if (K.ul) {
+            const int iu = t * NU + K.a;
+            v[V_YB] = w[L.YB + iu];
+            if (MODE == AFFINE || MODE == CORRECTOR) { v[V_SU] = w[L.SU + iu]; v[V_SL] = w[L.SL + iu]; v[V_ZU] = w[L.ZU + iu]; v[V_ZL] = w[L.ZL + iu]; }
+            if (MODE == AFFINE) { v[V_A] = w[L.RZU + iu]; v[V_B] = w[L.RZL + iu]; }
+            if (MODE == CORRECTOR) { v[V_A] = w[L.DSU + iu]; v[V_B] = w[L.DSL + iu]; v[V_C] = w[L.DZU + iu]; v[V_D] = w[L.DZL + iu]; }
+        }
+    };
     // dx_0 = -ry_init
     double dx = 0.0;
     if (K.xl) {
         if (MODE == INIT) dx = K.P.mx0[K.qp * NX + r];
         else if (MODE == AFFINE) dx = -w[L.RY + (T - 1) * NX + r];
     }
-    {   // dy_init = -(P_0 dx_0 + p_0)
-        const double *__restrict__ pr = fac + (long long)(K.xl ? r : 0) * NT;
-        double v = K.xl ? pvv[r] : 0.0;
-#pragma unroll
-        for (int c = 0; c < NX; ++c) v = fma(K.xl ? pr[c] : 0.0, rb(dx, c), v);
-        if (K.xl) {
-            double *o = w + L.DY + (T - 1) * NX + r;
-            *o = (MODE == CORRECTOR) ? *o - v : -v;
-        }
-    }
+    double cur[V_N], nxt[V_N];
+    load_vec(0, cur);
+    fetch_facF<C>(K, 0);
     for (int t = 0; t < T; ++t) {
-        const double *__restrict__ lr = fac + ((long long)t * NT + (r < NT ? r : 0)) * NT;
-        double lrow[NU];
+        double lrow[NU], prow[NX], frow[NT];
+        wait_vm();
+        const int rr = r < NT ? r : 0;
+        S::template cols<NT, NX, NT>(K.img, K.g, rr, lrow);
+        const double rd = K.ul ? K.img[S::template at<NT>(K.g, rr, 0)] : 0.0;
+        S::template cols<NT, 0, NX>(K.img, K.g, K.xl ? r : 0, prow);
+        if (t < T - 1) S::template cols<NX, 0, NT>(K.img + S::MAT, K.g, K.xl ? r : 0, frow);
+        wait_lds();
+        if (t < T - 1) { load_vec(t + 1, nxt); fetch_facF<C>(K, t + 1); }
+        {   // the multiplier behind x_t:  dy_{t-1} = P_t dx_t + p_t ;  t = 0:  dy_init = -(P_0 dx_0 + p_0)
+            double v = cur[V_PV];
 #pragma unroll
-        for (int b = 0; b < NU; ++b) lrow[b] = r < NT ? lr[NX + b] : 0.0;
-        const double rd = K.ul ? lr[0] : 0.0;
-        double zz = K.ul ? ybv[t * NU + K.a] : 0.0;
+            for (int c = 0; c < NX; ++c) v = fma(K.xl ? prow[c] : 0.0, rb(dx, c), v);
+            if (t == 0) v = -v;
+            if (K.xl) w[L.DY + (t >= 1 ? t - 1 : T - 1) * NX + r] = (MODE == CORRECTOR) ? cur[V_DYO] + v : v;
+        }
+#pragma unroll
+        for (int b = 0; b < NU; ++b) lrow[b] = r < NT ? lrow[b] : 0.0;
+        double zz = K.ul ? cur[V_YB] : 0.0;
 #pragma unroll
         for (int b = 0; b < NU; ++b) {
             const double wb = row_sum(K.xl ? lrow[b] * dx : 0.0);        // (Lxu' dx)[b]
@@ -466,23 +699,20 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K, double musig)
             if (r == j) yv = (zz - s) * rd;
         }
         const double dtau = K.xl ? dx : (K.ul ? -yv : 0.0);
-        if (r < NT) {
-            double *o = w + L.DX + t * NT + r;
-            *o = (MODE == CORRECTOR) ? *o + dtau : dtau;
-        }
+        if (r < NT) w[L.DX + t * NT + r] = (MODE == CORRECTOR) ? cur[V_DXO] + dtau : dtau;
         if (K.ul && MODE != ADJOINT) {
             const int iu = t * NU + K.a;
             if (MODE == INIT) {            // s = ds = -rz - G dx,  z = dz = -ds   (d = 1, rs = 0)
                 const double su = K.uu - dtau, sl = dtau - K.ulo;
                 w[L.SU + iu] = su; w[L.SL + iu] = sl; w[L.ZU + iu] = -su; w[L.ZL + iu] = -sl;
             } else {
-                const double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
+                const double su = cur[V_SU], sl = cur[V_SL], zu = cur[V_ZU], zl = cur[V_ZL];
                 double dsu, dsl, dzu, dzl;
                 if (MODE == AFFINE) {
-                    dsu = -w[L.RZU + iu] - dtau; dsl = -w[L.RZL + iu] + dtau;
+                    dsu = -cur[V_A] - dtau; dsl = -cur[V_B] + dtau;
                     dzu = -zu - zu / su * dsu;   dzl = -zl - zl / sl * dsl;
                 } else {
-                    const double asu = w[L.DSU + iu], asl = w[L.DSL + iu], azu = w[L.DZU + iu], azl = w[L.DZL + iu];
+                    const double asu = cur[V_A], asl = cur[V_B], azu = cur[V_C], azl = cur[V_D];
                     const double rsu = (-musig + asu * azu) / su, rsl = (-musig + asl * azl) / sl;
                     const double csu = -dtau, csl = dtau;
                     dsu = asu + csu; dsl = asl + csl;
@@ -497,23 +727,13 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K, double musig)
             }
         }
         if (t < T - 1) {
-            double frow[NT];
-            const double *__restrict__ fp = K.Frow(t);
 #pragma unroll
-            for (int c = 0; c < NT; ++c) frow[c] = K.xl ? fp[c] : 0.0;
-            double q, e;
-            stage_rhs<C, MODE>(K, t, musig, q, e);
-            const double dxn = mv_row<NT>(frow, dtau) + e;
-            const double *__restrict__ pr = fac + ((long long)(t + 1) * NT + (K.xl ? r : 0)) * NT;
-            double v = K.xl ? pvv[(t + 1) * NX + r] : 0.0;
-#pragma unroll
-            for (int c = 0; c < NX; ++c) v = fma(K.xl ? pr[c] : 0.0, rb(dxn, c), v);
-            if (K.xl) {
-                double *o = w + L.DY + t * NX + r;
-                *o = (MODE == CORRECTOR) ? *o + v : v;
-            }
+            for (int c = 0; c < NT; ++c) frow[c] = K.xl ? frow[c] : 0.0;
+            const double dxn = mv_row<NT>(frow, dtau) + (USE_E ? cur[V_E] : 0.0);
             dx = K.xl ? dxn : 0.0;
         }
+#pragma unroll
+        for (int i = 0; i < V_N; ++i) cur[i] = nxt[i];
     }
     return ratio;
 }
@@ -556,8 +776,11 @@ __device__ __forceinline__ void copy_best(const Ctx<C> &K, double *snap)
     ew_copy(w + L.BX, w + L.X, len, r);          // BX, BY, BSU, BSL, BZU, BZL mirror X .. ZL
 }
 
-template <class C>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void forward_kernel(KParams P, int T)
+#ifndef DQP_RIC_WPE
+#define DQP_RIC_WPE 2
+#endif
+template <class C, bool DYN>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE, DQP_RIC_WPE))) void forward_kernel(KParams P, int T)
 {
     constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
     const int lane = threadIdx.x, r = lane & 15;
@@ -575,8 +798,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const Lay L = layout(NX, NU, T);
     // a duplicated (padding) row works on its own copy of the last problem's scratch: rows must not race
     const long long slot = (long long)blockIdx.x * 4 + (lane >> 4);
+    __shared__ __attribute__((aligned(16))) double img[Stage<C>::TOTAL];
+    const long long qp0 = (long long)blockIdx.x * 4;
     Ctx<C> K = {P, P.workspace + slot * (long long)L.total, L, qp, r, T, r < NX, r >= NX && r < NT, live,
-                (r >= NX && r < NT) ? r - NX : 0, 0.0, 0.0};
+                (r >= NX && r < NT) ? r - NX : 0, 0.0, 0.0,
+                lane, lane >> 4, (int)min(3LL, (long long)P.B - 1 - qp0), qp0, P.workspace + qp0 * (long long)L.total, img};
     K.uu = P.muu[K.a]; K.ulo = P.mul[K.a];
     double *w = K.w;
     const int nineq = 2 * T * NU;
@@ -606,7 +832,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     int nNot = 0, iters = 0;
     for (int it = 0; it < maxIter; ++it) {
         double nx2, nz2, ny2, sz;
-        const bool pd = factor_fused<C>(K, nx2, nz2, ny2, sz);      // residuals + factorisation + affine rhs
+        const bool pd = factor_fused<C, DYN>(K, nx2, nz2, ny2, sz);      // residuals + factorisation + affine rhs
         nx2 = row_sum(nx2); nz2 = row_sum(nz2); ny2 = row_sum(ny2); sz = row_sum(sz);
         const double mu = fabs(sz / nineq);
         const double resid = sqrt(nz2) + sqrt(ny2) + sqrt(nx2) + nineq * mu;
@@ -678,8 +904,11 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P, int T)
     if (!live) qp = P.B - 1;
     const Lay L = layout(NX, NU, T);
     const long long slot = (long long)blockIdx.x * 4 + (lane >> 4);
+    __shared__ __attribute__((aligned(16))) double img[Stage<C>::TOTAL];
+    const long long qp0 = (long long)blockIdx.x * 4;
     Ctx<C> K = {P, P.workspace + slot * (long long)L.total, L, qp, r, T, r < NX, r >= NX && r < NT, live,
-                (r >= NX && r < NT) ? r - NX : 0, 0.0, 0.0};
+                (r >= NX && r < NT) ? r - NX : 0, 0.0, 0.0,
+                lane, lane >> 4, (int)min(3LL, (long long)P.B - 1 - qp0), qp0, P.workspace + qp0 * (long long)L.total, img};
     double *w = K.w;
     const int nz = T * NT, neq = T * NX, hm = T * NU;
     for (int i = r; i < hm; i += 16) {
@@ -762,9 +991,11 @@ template <class C, class Kern> int launch(Kern kernel, const KParams &P, int T, 
 }  // namespace ric
 
 // size table: (n_state, n_ctrl) pairs with a stage-wise kernel
+#ifndef DQP_RIC_SIZES
 #define DQP_RIC_SIZES                                                                                   \
     X(12, 4) X(3, 3) X(3, 1) X(4, 1) X(6, 1) X(2, 1) X(4, 2) X(5, 1) X(8, 1) X(2, 2) X(3, 2) X(6, 2) X(8, 2) X(6, 3)  \
     X(4, 4) X(8, 4) X(10, 4) X(12, 2)
+#endif
 
 bool ric_supported(int n, int m)
 {
@@ -781,7 +1012,15 @@ long long ric_workspace_doubles(int n, int m, int T)
 
 int ric_forward(const KParams &P, void *stream)
 {
-#define X(a, b) if (P.mn == a && P.mm == b) return ric::launch<ric::Cfg<a, b>>(ric::forward_kernel<ric::Cfg<a, b>>, P, P.mT, stream);
+    // the true-dynamics residual of a registered model is its own instantiation: the model's registers
+    // (an RK4 step of the quadrotor) would otherwise be spilled around on the linear path too
+#define X(a, b)                                                                                                       \
+    if (P.mn == a && P.mm == b) {                                                                                     \
+        using Cf = ric::Cfg<a, b>;                                                                                    \
+        if constexpr (ric::has_model<Cf>())                                                                           \
+            if (P.dynId) return ric::launch<Cf>(ric::forward_kernel<Cf, true>, P, P.mT, stream);                      \
+        return P.dynId ? 1 : ric::launch<Cf>(ric::forward_kernel<Cf, false>, P, P.mT, stream);                        \
+    }
     DQP_RIC_SIZES
 #undef X
     return 1;
