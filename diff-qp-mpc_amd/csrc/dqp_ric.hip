@@ -51,7 +51,7 @@ struct Lay {
     int RX, RY, RZU, RZL;                // residuals of the iterate
     int DX, DY, DSU, DSL, DZU, DZL;      // step (affine, then affine + corrector)
     int BX, BY, BSU, BSL, BZU, BZL;      // best iterate
-    int FAC, PV, YB;                     // per knot: eliminated H rows (NT x NT), p_t (NX), Luu^-1 h_u (NU)
+    int FACP, FACL, PV, YB;              // per knot: P_t (NX x NX), [Lxu ; Luu] (NT x NU, 1 / L_jj on the diagonal), p_t (NX), Luu^-1 h_u (NU)
     int total;
 };
 __host__ __device__ inline Lay layout(int nx, int nu, int T)
@@ -64,7 +64,8 @@ __host__ __device__ inline Lay layout(int nx, int nu, int T)
     L.RX = take(T * nt); L.RY = take(T * nx); L.RZU = take(T * nu); L.RZL = take(T * nu);
     L.DX = take(T * nt); L.DY = take(T * nx); L.DSU = take(T * nu); L.DSL = take(T * nu); L.DZU = take(T * nu); L.DZL = take(T * nu);
     L.BX = take(T * nt); L.BY = take(T * nx); L.BSU = take(T * nu); L.BSL = take(T * nu); L.BZU = take(T * nu); L.BZL = take(T * nu);
-    L.FAC = take(T * nt * nt); L.PV = take(T * nx); L.YB = take(T * nu);
+    o = (o + 1) & ~1; L.FACP = take(T * nx * nx); o = (o + 1) & ~1; L.FACL = take(T * nt * nu);     // 16-byte aligned: DMA sources
+    L.PV = take(T * nx); L.YB = take(T * nu);
     L.total = (o + 1) & ~1;
     return L;
 }
@@ -87,7 +88,8 @@ template <class C> struct Ctx {
     // knot t of the wavefront's four problems: contiguous in the (T, B, ., .) inputs
     __device__ const double *Cblk(int t) const { return P.mC + ((long long)t * P.B + qp0) * (C::NT * C::NT); }
     __device__ const double *Fblk(int t) const { return P.mF + ((long long)t * P.B + qp0) * (C::NX * C::NT); }
-    __device__ const double *FACblk(int t) const { return w0 + L.FAC + (long long)t * (C::NT * C::NT); }
+    __device__ const double *Pblk(int t) const { return w0 + L.FACP + (long long)t * (C::NX * C::NX); }
+    __device__ const double *Lblk(int t) const { return w0 + L.FACL + (long long)t * (C::NT * C::NU); }
 };
 
 // A copy of the context whose per-lane address roots the compiler must treat as new values: every
@@ -120,23 +122,14 @@ typedef __attribute__((address_space(3))) void lvoid_t;
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <class C> struct Stage {
-    static constexpr int NX = C::NX, NT = C::NT;
-    static constexpr int PIECE = (NT % 2 == 0) ? 16 : 4;            // bytes per lane of one DMA instruction
-    static constexpr int PPR = NT * 8 / PIECE;                       // pieces per matrix row
+// one kind of matrix in the stage: rows of RL doubles
+template <int RL> struct Img {
+    static constexpr int PIECE = (RL % 2 == 0) ? 16 : 4;            // bytes per lane of one DMA instruction
+    static constexpr int PPR = RL * 8 / PIECE;                       // pieces per matrix row
     // rows of 2^k 16-byte pieces start on few distinct bank groups: piece j of row `row` sits at j ^ swz(row)
     static constexpr int SWZ_DIV = (PIECE == 16 && PPR > 1 && PPR <= 8 && (PPR & (PPR - 1)) == 0) ? 16 / PPR : 0;
-    static constexpr int pad64(int pieces) { return (pieces + 63) / 64 * 64; }
-    static constexpr int MAT = pad64(4 * NT * PPR) * PIECE / 8;      // doubles
-    static constexpr int FMT = pad64(4 * NX * PPR) * PIECE / 8;
-    static constexpr int TOTAL = MAT + FMT;
+    static constexpr int doubles(int rows) { return (4 * rows * PPR + 63) / 64 * 64 * PIECE / 8; }   // image of four problems
     __device__ __forceinline__ static int swz(int row) { return SWZ_DIV ? (row / (SWZ_DIV ? SWZ_DIV : 1)) & (PPR - 1) : 0; }
-    // element (row, c) of place g in an image of ROWS-row matrices
-    template <int ROWS> __device__ __forceinline__ static int at(int g, int row, int c)
-    {
-        if constexpr (PIECE == 16) return (g * ROWS + row) * NT + ((((c >> 1) ^ swz(row)) << 1) | (c & 1));
-        else return (g * ROWS + row) * NT + c;
-    }
     // columns [C0, C1) of row `row` of place g.  With the swizzle, piece j of the row is at index
     // (base | s << 1) ^ (j << 1) (base is a multiple of the row length 2 PPR, a power of two there): one
     // XOR per piece off a single register, which is handed to the compiler as a new value at every call --
@@ -147,7 +140,7 @@ template <class C> struct Stage {
     {
         static_assert(N == C1 - C0, "");
         if constexpr (PIECE == 16) {
-            int root = ((g * ROWS + row) * NT) | (swz(row) << 1);
+            int root = ((g * ROWS + row) * RL) | (swz(row) << 1);
             asm volatile("" : "+v"(root));
 #pragma unroll
             for (int j = C0 / 2; j <= (C1 - 1) / 2; ++j) {
@@ -156,7 +149,7 @@ template <class C> struct Stage {
                 if (2 * j + 1 >= C0 && 2 * j + 1 < C1) out[2 * j + 1 - C0] = v.y;
             }
         } else {
-            int root = (g * ROWS + row) * NT;
+            int root = (g * ROWS + row) * RL;
             asm volatile("" : "+v"(root));
 #pragma unroll
             for (int c = C0; c < C1; ++c) out[c - C0] = img[root + c];
@@ -166,15 +159,15 @@ template <class C> struct Stage {
     template <int ROWS>
     __device__ __forceinline__ static void column(const double *img, int g, int col, double (&out)[ROWS])
     {
-        int root = g * ROWS * NT + col;
+        int root = g * ROWS * RL + col;
         asm volatile("" : "+v"(root));
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-            if constexpr (PIECE == 16 && SWZ_DIV != 0) out[i] = img[(root ^ (((i / SWZ_DIV) & (PPR - 1)) << 1)) + i * NT];
-            else out[i] = img[root + i * NT];
+            if constexpr (PIECE == 16 && SWZ_DIV != 0) out[i] = img[(root ^ (((i / SWZ_DIV) & (PPR - 1)) << 1)) + i * RL];
+            else out[i] = img[root + i * RL];
         }
     }
-    // issue the DMA of one knot's ROWS x NT matrices: place q's matrix is at base + min(q, qmax) * qstride_bytes
+    // issue the DMA of one knot's ROWS x RL matrices: place q's matrix is at base + min(q, qmax) * qstride_bytes
     template <int ROWS>
     __device__ __forceinline__ static void fetch(double *img, const double *base, int qstride_bytes, int qmax, int lane)
     {
@@ -191,6 +184,18 @@ template <class C> struct Stage {
             else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
         }
     }
+};
+
+// the wavefront's image: [C_t | F_t] while factorising, [P_t | L_t | F_t] in the vector sweeps
+template <class C> struct Stage {
+    static constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    using MC = Img<NT>;             // C_t: NT rows of NT
+    using MF = Img<NT>;             // F_t: NX rows of NT
+    using MP = Img<NX>;             // cost-to-go P_t: NX rows of NX
+    using ML = Img<NU>;             // [Lxu ; Luu] with 1 / L_jj on the diagonal: NT rows of NU
+    static constexpr int OL = MP::doubles(NX);
+    static constexpr int OF = MC::doubles(NT) > OL + ML::doubles(NT) ? MC::doubles(NT) : OL + ML::doubles(NT);
+    static constexpr int TOTAL = OF + MF::doubles(NX);
 };
 
 // y[r] = sum_c row[c] * v[c]  (row = this lane's matrix row, v distributed)
@@ -226,7 +231,7 @@ __device__ __forceinline__ void add_FtPF(double (&H)[C::NT], const double (&Pn)[
     }
 }
 
-// this lane's row of the knot's NT x NT matrix, its row and its column of F_t, out of the stage
+// this lane's row of C_t, its row and its column of F_t, out of the stage
 template <class C>
 __device__ __forceinline__ void stage_rows(const Ctx<C> &K, bool withF, double (&H)[C::NT], double (&frow)[C::NT],
                                            double (&fcol)[C::NX])
@@ -234,10 +239,10 @@ __device__ __forceinline__ void stage_rows(const Ctx<C> &K, bool withF, double (
     using S = Stage<C>;
     constexpr int NX = C::NX, NT = C::NT;
     const int r = K.r;
-    S::template cols<NT, 0, NT>(K.img, K.g, r < NT ? r : 0, H);
+    S::MC::template cols<NT, 0, NT>(K.img, K.g, r < NT ? r : 0, H);
     if (withF) {
-        S::template cols<NX, 0, NT>(K.img + S::MAT, K.g, K.xl ? r : 0, frow);
-        S::template column<NX>(K.img + S::MAT, K.g, r < NT ? r : 0, fcol);
+        S::MF::template cols<NX, 0, NT>(K.img + S::OF, K.g, K.xl ? r : 0, frow);
+        S::MF::template column<NX>(K.img + S::OF, K.g, r < NT ? r : 0, fcol);
 #pragma unroll
         for (int c = 0; c < NT; ++c) frow[c] = K.xl ? frow[c] : 0.0;
 #pragma unroll
@@ -247,14 +252,42 @@ __device__ __forceinline__ void stage_rows(const Ctx<C> &K, bool withF, double (
 template <class C> __device__ __forceinline__ void fetch_CF(const Ctx<C> &K, int t)
 {
     using S = Stage<C>;
-    S::template fetch<C::NT>(K.img, K.Cblk(t), C::NT * C::NT * 8, K.qmax, K.lane);
-    if (t < K.T - 1) S::template fetch<C::NX>(K.img + S::MAT, K.Fblk(t), C::NX * C::NT * 8, K.qmax, K.lane);
+    S::MC::template fetch<C::NT>(K.img, K.Cblk(t), C::NT * C::NT * 8, K.qmax, K.lane);
+    if (t < K.T - 1) S::MF::template fetch<C::NX>(K.img + S::OF, K.Fblk(t), C::NX * C::NT * 8, K.qmax, K.lane);
 }
-template <class C> __device__ __forceinline__ void fetch_facF(const Ctx<C> &K, int t)
+// the factor rows of knot t (P_t only where the sweep multiplies by it) and F_t
+template <class C, bool WITHP> __device__ __forceinline__ void fetch_facF(const Ctx<C> &K, int t)
 {
     using S = Stage<C>;
-    S::template fetch<C::NT>(K.img, K.FACblk(t), K.L.total * 8, 3, K.lane);
-    if (t < K.T - 1) S::template fetch<C::NX>(K.img + S::MAT, K.Fblk(t), C::NX * C::NT * 8, K.qmax, K.lane);
+    if (WITHP) S::MP::template fetch<C::NX>(K.img, K.Pblk(t), K.L.total * 8, 3, K.lane);
+    S::ML::template fetch<C::NT>(K.img + S::OL, K.Lblk(t), K.L.total * 8, 3, K.lane);
+    if (t < K.T - 1) S::MF::template fetch<C::NX>(K.img + S::OF, K.Fblk(t), C::NX * C::NT * 8, K.qmax, K.lane);
+}
+// this lane's row of [Lxu ; Luu] and, on a control lane, 1 / L_jj (kept on the diagonal)
+template <class C> __device__ __forceinline__ double stage_L(const Ctx<C> &K, double (&lrow)[C::NU])
+{
+    using S = Stage<C>;
+    S::ML::template cols<C::NT, 0, C::NU>(K.img + S::OL, K.g, K.r < C::NT ? K.r : 0, lrow);
+    double rd = 0.0;
+#pragma unroll
+    for (int b = 0; b < C::NU; ++b) rd = (K.ul && K.a == b) ? lrow[b] : rd;
+    return rd;
+}
+// the factor rows of one knot out of the registers: H = [P | Lxu] on the state lanes, [. | Luu] on the control lanes
+template <class C> __device__ __forceinline__ void store_fac(const Ctx<C> &K, double *w, int t, const double (&H)[C::NT], double rdj)
+{
+    constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
+    const int r = K.r;
+    if (K.xl) {
+        double *o = w + K.L.FACP + ((long long)t * NX + r) * NX;
+#pragma unroll
+        for (int c = 0; c < NX; ++c) o[c] = H[c];
+    }
+    if (r < NT) {
+        double *o = w + K.L.FACL + ((long long)t * NT + r) * NU;
+#pragma unroll
+        for (int b = 0; b < NU; ++b) o[b] = (r == NX + b) ? rdj : H[NX + b];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -310,12 +343,7 @@ __device__ __forceinline__ bool factor(const Ctx<C> &K0, bool unit, bool clampd)
             H[j] = lij;
             if (r == j) rdj_keep = rdj;
         }
-        if (K.ul) H[0] = rdj_keep;                          // control lanes: 1 / L_jj parked in an unused slot
-        if (r < NT) {
-            double *o = w + L.FAC + ((long long)t * NT + r) * NT;
-#pragma unroll
-            for (int c = 0; c < NT; ++c) o[c] = H[c];
-        }
+        store_fac<C>(K, w, t, H, rdj_keep);
 #pragma unroll
         for (int c = 0; c < NX; ++c) Pn[c] = K.xl ? H[c] : 0.0;
         dd = dn;
@@ -494,12 +522,7 @@ __device__ __forceinline__ bool factor_fused(const Ctx<C> &K0, double &nx2, doub
             const double hj = rb(h, j) * rdj;
             h = (r == j) ? hj : ((r < NX || (r > j && r < NT)) ? fma(-lij, hj, h) : h);
         }
-        if (K.ul) H[0] = rdj_keep;
-        if (r < NT) {
-            double *o = w + L.FAC + ((long long)t * NT + r) * NT;
-#pragma unroll
-            for (int c = 0; c < NT; ++c) o[c] = H[c];
-        }
+        store_fac<C>(K, w, t, H, rdj_keep);
         if (K.xl) w[L.PV + t * NX + r] = h;
         if (K.ul) w[L.YB + t * NU + K.a] = h;
         pn = K.xl ? h : 0.0;
@@ -575,21 +598,19 @@ __device__ __forceinline__ void sweep_back(const Ctx<C> &K0, double musig)
     for (int c = 0; c < NX; ++c) Pn[c] = 0.0;
     double cur[R_N], nxt[R_N];
     rhs_load<C, MODE, true, USE_E>(K, T - 1, cur);
-    fetch_facF<C>(K, T - 1);
+    fetch_facF<C, USE_E>(K, T - 1);
     for (int t = T - 1; t >= 0; --t) {
         double fcol[NX], lcol[NU], prow[NX];
         wait_vm();
-        const int rr = r < NT ? r : 0;
-        S::template cols<NT, NX, NT>(K.img, K.g, rr, lcol);
-        const double rd = K.ul ? K.img[S::template at<NT>(K.g, rr, 0)] : 0.0;
-        if (USE_E) S::template cols<NT, 0, NX>(K.img, K.g, K.xl ? r : 0, prow);
+        const double rd = stage_L<C>(K, lcol);
+        if (USE_E) S::MP::template cols<NX, 0, NX>(K.img, K.g, K.xl ? r : 0, prow);
         if (t < T - 1) {
-            S::template column<NX>(K.img + S::MAT, K.g, rr, fcol);
+            S::MF::template column<NX>(K.img + S::OF, K.g, r < NT ? r : 0, fcol);
 #pragma unroll
             for (int i = 0; i < NX; ++i) fcol[i] = r < NT ? fcol[i] : 0.0;
         }
         wait_lds();
-        if (t > 0) { rhs_load<C, MODE, true, USE_E>(K, t - 1, nxt); fetch_facF<C>(K, t - 1); }
+        if (t > 0) { rhs_load<C, MODE, true, USE_E>(K, t - 1, nxt); fetch_facF<C, USE_E>(K, t - 1); }
         double h = rhs_q<C, MODE>(K, cur, musig);
         if (t < T - 1) {
             double v = pn;
@@ -666,17 +687,15 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K0, double musig)
     }
     double cur[V_N], nxt[V_N];
     load_vec(0, cur);
-    fetch_facF<C>(K, 0);
+    fetch_facF<C, true>(K, 0);
     for (int t = 0; t < T; ++t) {
         double lrow[NU], prow[NX], frow[NT];
         wait_vm();
-        const int rr = r < NT ? r : 0;
-        S::template cols<NT, NX, NT>(K.img, K.g, rr, lrow);
-        const double rd = K.ul ? K.img[S::template at<NT>(K.g, rr, 0)] : 0.0;
-        S::template cols<NT, 0, NX>(K.img, K.g, K.xl ? r : 0, prow);
-        if (t < T - 1) S::template cols<NX, 0, NT>(K.img + S::MAT, K.g, K.xl ? r : 0, frow);
+        const double rd = stage_L<C>(K, lrow);
+        S::MP::template cols<NX, 0, NX>(K.img, K.g, K.xl ? r : 0, prow);
+        if (t < T - 1) S::MF::template cols<NX, 0, NT>(K.img + S::OF, K.g, K.xl ? r : 0, frow);
         wait_lds();
-        if (t < T - 1) { load_vec(t + 1, nxt); fetch_facF<C>(K, t + 1); }
+        if (t < T - 1) { load_vec(t + 1, nxt); fetch_facF<C, true>(K, t + 1); }
         {   // the multiplier behind x_t:  dy_{t-1} = P_t dx_t + p_t ;  t = 0:  dy_init = -(P_0 dx_0 + p_0)
             double v = cur[V_PV];
 #pragma unroll
@@ -738,28 +757,54 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K0, double musig)
     return ratio;
 }
 
-// element-wise helpers over the constraint arrays (length 2 T NU, lanes strided)
-// element-wise helpers over per-QP arrays, lanes strided, four independent loads in flight per lane
-// (a plain `for (i = r; i < n; i += 16) dst[i] = src[i]` waits out one memory latency per element:
-// nothing tells the compiler that dst and src are different regions of the workspace)
-__device__ __forceinline__ void ew_copy(double *__restrict__ dst, const double *__restrict__ src, int n, int r)
+// element-wise helpers over per-QP arrays, lanes strided.  A plain `for (i = r; i < n; i += 16) dst[i] = src[i]`
+// waits out one memory latency per element (nothing tells the compiler that dst and src are different
+// regions of the workspace); these keep EW_DEPTH independent loads per lane in flight -- the passes
+// between the sweeps were 15-20 % of an iteration at four.
+constexpr int EW_DEPTH = 16;
+__device__ __forceinline__ void ew_copy(double *__restrict__ dst, double *__restrict__ dst2, const double *__restrict__ src,
+                                        int n, int r)
 {
     int i = r;
-    for (; i + 48 < n; i += 64) {
-        const double a = src[i], b = src[i + 16], c = src[i + 32], d = src[i + 48];
-        dst[i] = a; dst[i + 16] = b; dst[i + 32] = c; dst[i + 48] = d;
+    for (; i + 16 * (EW_DEPTH - 1) < n; i += 16 * EW_DEPTH) {
+        double v[EW_DEPTH];
+#pragma unroll
+        for (int k = 0; k < EW_DEPTH; ++k) v[k] = src[i + 16 * k];
+#pragma unroll
+        for (int k = 0; k < EW_DEPTH; ++k) dst[i + 16 * k] = v[k];
+        if (dst2) {
+#pragma unroll
+            for (int k = 0; k < EW_DEPTH; ++k) dst2[i + 16 * k] = v[k];
+        }
     }
-    for (; i < n; i += 16) dst[i] = src[i];
+    double v[EW_DEPTH];
+#pragma unroll
+    for (int k = 0; k < EW_DEPTH; ++k) v[k] = i + 16 * k < n ? src[i + 16 * k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < EW_DEPTH; ++k) {
+        if (i + 16 * k < n) {
+            dst[i + 16 * k] = v[k];
+            if (dst2) dst2[i + 16 * k] = v[k];
+        }
+    }
 }
 __device__ __forceinline__ void ew_axpy(double *__restrict__ y, const double *__restrict__ x, double alpha, int n, int r)
 {
+    constexpr int D = EW_DEPTH / 2;
     int i = r;
-    for (; i + 48 < n; i += 64) {
-        const double a = x[i], b = x[i + 16], c = x[i + 32], d = x[i + 48];
-        const double ya = y[i], yb = y[i + 16], yc = y[i + 32], yd = y[i + 48];
-        y[i] = fma(alpha, a, ya); y[i + 16] = fma(alpha, b, yb); y[i + 32] = fma(alpha, c, yc); y[i + 48] = fma(alpha, d, yd);
+    for (; i + 16 * (D - 1) < n; i += 16 * D) {
+        double xv[D], yv[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) { xv[k] = x[i + 16 * k]; yv[k] = y[i + 16 * k]; }
+#pragma unroll
+        for (int k = 0; k < D; ++k) y[i + 16 * k] = fma(alpha, xv[k], yv[k]);
     }
-    for (; i < n; i += 16) y[i] = fma(alpha, x[i], y[i]);
+    double xv[D], yv[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) { const bool in = i + 16 * k < n; xv[k] = in ? x[i + 16 * k] : 0.0; yv[k] = in ? y[i + 16 * k] : 0.0; }
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+        if (i + 16 * k < n) y[i + 16 * k] = fma(alpha, xv[k], yv[k]);
 }
 
 // the iterate (X, Y, SU, SL, ZU, ZL: contiguous at the head of the layout) -> the best-iterate arrays,
@@ -772,8 +817,7 @@ __device__ __forceinline__ void copy_best(const Ctx<C> &K, double *snap)
     const Lay &L = K.L;
     const int T = K.T, r = K.r;
     const int len = T * (NT + NX + 4 * NU);
-    if (snap && K.live) ew_copy(snap, w, len, r);
-    ew_copy(w + L.BX, w + L.X, len, r);          // BX, BY, BSU, BSL, BZU, BZL mirror X .. ZL
+    ew_copy(w + L.BX, (snap && K.live) ? snap : nullptr, w + L.X, len, r);      // BX, BY, BSU, BSL, BZU, BZL mirror X .. ZL
 }
 
 #ifndef DQP_RIC_WPE
@@ -813,8 +857,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
     sweep_back<C, INIT>(K, 0.0);
     sweep_fwd<C, INIT>(K, 0.0);
     {
-        ew_copy(w + L.X, w + L.DX, T * NT, r);
-        ew_copy(w + L.Y, w + L.DY, T * NX, r);
+        ew_copy(w + L.X, nullptr, w + L.DX, T * NT, r);
+        ew_copy(w + L.Y, nullptr, w + L.DY, T * NX, r);
         double ms = INFINITY, mz = INFINITY;
         for (int i = r; i < T * NU; i += 16) {
             ms = fmin(ms, fmin(w[L.SU + i], w[L.SL + i]));
@@ -857,6 +901,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
         double ra = row_min(sweep_fwd<C, AFFINE>(K, 0.0));
         const double alpha_a = fmin(ra, 1.0);
         double t3 = 0.0;
+#pragma unroll 4
         for (int i = r; i < T * NU; i += 16) {
             t3 = fma(w[L.SU + i] + alpha_a * w[L.DSU + i], w[L.ZU + i] + alpha_a * w[L.DZU + i], t3);
             t3 = fma(w[L.SL + i] + alpha_a * w[L.DSL + i], w[L.ZL + i] + alpha_a * w[L.DZL + i], t3);
