@@ -32,6 +32,7 @@ DQP_OK = 0
 DQP_FLAG_DENSE_BACKWARD = 1
 DQP_FLAG_GENERIC_ONLY = 2
 DQP_FLAG_NO_NULLSPACE = 4
+DQP_FLAG_RIC_GLOBAL_WS = 64
 DQP_FLAG_BACKWARD_CTX = 8
 DQP_FLAG_BATCH_TERMINATION = 16
 DQP_FLAG_HISTORY_ONLY = 32

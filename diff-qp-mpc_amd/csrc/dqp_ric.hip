@@ -40,8 +40,11 @@ namespace ric {
 
 using namespace dqp::r16;
 
-template <int NX_, int NU_> struct Cfg {
+// WSL: the per-QP workspace (iterates, directions, factors) lives in LDS instead of the caller's buffer --
+// the forward kernel of short horizons, where it fits beside the stage and a knot step is latency, not bandwidth
+template <int NX_, int NU_, bool WSL_ = false> struct Cfg {
     static constexpr int NX = NX_, NU = NU_, NT = NX_ + NU_;
+    static constexpr bool WSL = WSL_;
     static_assert(NT <= 16, "a knot must fit a 16-lane DPP row");
 };
 
@@ -72,6 +75,8 @@ __host__ __device__ inline Lay layout(int nx, int nu, int T)
 
 enum Mode { INIT = 0, AFFINE = 1, CORRECTOR = 2, ADJOINT = 3 };
 
+extern __shared__ __attribute__((aligned(16))) double lds_dyn[];       // Cfg<., ., true>: [C | F | c | f | four workspaces]
+
 template <class C> struct Ctx {
     const KParams &P;
     double *w;                      // this QP's workspace
@@ -84,7 +89,13 @@ template <class C> struct Ctx {
     int lane, g, qmax;              // lane, place of its problem in the wavefront, last place with a problem of its own
     long long qp0;                  // problem at place 0
     double *w0;                     // workspace of place 0 (places are L.total doubles apart)
-    double *img;                    // the wavefront's LDS stage (Stage<C>)
+    double *img;                    // the wavefront's LDS stage (Stage<C>); WSL: every knot's C_t, then every F_t
+    int rf;                         // WSL: where the F_t images start in img
+    const double *lc, *lf;          // WSL: c and f of the four problems, [(t * 4 + place) * NT or NX + r]
+    __device__ const double *imgC(int t) const { return C::WSL ? img + t * (4 * C::NT * C::NT) : img; }
+    __device__ const double *imgF(int t) const;
+    __device__ double cvec(int t) const { return C::WSL ? lc[(t * 4 + g) * C::NT + r] : P.mc[((long long)t * P.B + qp) * C::NT + r]; }
+    __device__ double fvec(int t) const { return C::WSL ? lf[(t * 4 + g) * C::NX + r] : P.mf[((long long)t * P.B + qp) * C::NX + r]; }
     // knot t of the wavefront's four problems: contiguous in the (T, B, ., .) inputs
     __device__ const double *Cblk(int t) const { return P.mC + ((long long)t * P.B + qp0) * (C::NT * C::NT); }
     __device__ const double *Fblk(int t) const { return P.mF + ((long long)t * P.B + qp0) * (C::NX * C::NT); }
@@ -99,7 +110,13 @@ template <class C> struct Ctx {
 template <class C> __device__ __forceinline__ Ctx<C> fresh(const Ctx<C> &K0)
 {
     Ctx<C> K = K0;
-    asm volatile("" : "+v"(K.r), "+v"(K.lane), "+v"(K.g), "+v"(K.w));
+    if constexpr (C::WSL) {         // an LDS pointer stays an LDS pointer (ds_ instead of flat_ accesses)
+        int off = (int)(K0.w - lds_dyn);
+        asm volatile("" : "+v"(K.r), "+v"(K.lane), "+v"(K.g), "+v"(off));
+        K.w = lds_dyn + off;
+    } else {
+        asm volatile("" : "+v"(K.r), "+v"(K.lane), "+v"(K.g), "+v"(K.w));
+    }
     K.xl = K.r < C::NX;
     K.ul = K.r >= C::NX && K.r < C::NT;
     K.a = K.ul ? K.r - C::NX : 0;
@@ -184,6 +201,27 @@ template <int RL> struct Img {
             else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
         }
     }
+    // the same for `count` consecutive knots at once (knot stride tstride_bytes in the source), images back to
+    // back without padding: the resident copy of a short-horizon problem
+    template <int ROWS>
+    __device__ __forceinline__ static void fetch_all(double *img, const double *base, long long tstride_bytes, int qstride_bytes,
+                                                     int qmax, int lane, int count)
+    {
+        constexpr int PIECES = 4 * ROWS * PPR;
+        const int total = count * PIECES;
+        for (int k = 0; k * 64 < total; ++k) {
+            int p = k * 64 + lane;
+            p = p < total ? p : total - 1;
+            const int t = p / PIECES, pp = p % PIECES;
+            const int rowg = pp / PPR, j = pp % PPR, q = rowg / ROWS, row = rowg % ROWS;
+            const long long off = t * tstride_bytes + (q < qmax ? q : qmax) * qstride_bytes + (row * PPR + (j ^ swz(row))) * PIECE;
+            gvoid_t *src = (gvoid_t *)(reinterpret_cast<const char *>(base) + off);
+            lvoid_t *dst = (lvoid_t *)(img + k * (64 * PIECE / 8));
+            if constexpr (PIECE == 16) __builtin_amdgcn_global_load_lds(src, dst, 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds(src, dst, 4, 0, 0);
+        }
+    }
+    static constexpr __host__ __device__ int resident_doubles(int rows, int count) { return (count * 4 * rows * PPR + 63) / 64 * 64 * PIECE / 8; }
 };
 
 // the wavefront's image: [C_t | F_t] while factorising, [P_t | L_t | F_t] in the vector sweeps
@@ -196,7 +234,17 @@ template <class C> struct Stage {
     static constexpr int OL = MP::doubles(NX);
     static constexpr int OF = MC::doubles(NT) > OL + ML::doubles(NT) ? MC::doubles(NT) : OL + ML::doubles(NT);
     static constexpr int TOTAL = OF + MF::doubles(NX);
+    // WSL (everything of a short-horizon problem in LDS): [C_0 .. C_{T-1} | F_0 .. F_{T-2} | c | f | four workspaces]
+    static __host__ __device__ int res_f(int T) { return MC::resident_doubles(NT, T); }
+    static __host__ __device__ int res_c(int T) { return res_f(T) + MF::resident_doubles(NX, T - 1 > 0 ? T - 1 : 1); }
+    static __host__ __device__ int res_fv(int T) { return res_c(T) + T * 4 * NT; }
+    static __host__ __device__ int res_ws(int T) { return (res_fv(T) + T * 4 * NX + 1) & ~1; }
 };
+
+template <class C> __device__ __forceinline__ const double *Ctx<C>::imgF(int t) const
+{
+    return C::WSL ? img + rf + t * (4 * C::NX * C::NT) : img + Stage<C>::OF;
+}
 
 // y[r] = sum_c row[c] * v[c]  (row = this lane's matrix row, v distributed)
 template <int N> __device__ __forceinline__ double mv_row(const double (&row)[N], double v)
@@ -233,16 +281,16 @@ __device__ __forceinline__ void add_FtPF(double (&H)[C::NT], const double (&Pn)[
 
 // this lane's row of C_t, its row and its column of F_t, out of the stage
 template <class C>
-__device__ __forceinline__ void stage_rows(const Ctx<C> &K, bool withF, double (&H)[C::NT], double (&frow)[C::NT],
+__device__ __forceinline__ void stage_rows(const Ctx<C> &K, int t, bool withF, double (&H)[C::NT], double (&frow)[C::NT],
                                            double (&fcol)[C::NX])
 {
     using S = Stage<C>;
     constexpr int NX = C::NX, NT = C::NT;
     const int r = K.r;
-    S::MC::template cols<NT, 0, NT>(K.img, K.g, r < NT ? r : 0, H);
+    S::MC::template cols<NT, 0, NT>(K.imgC(t), K.g, r < NT ? r : 0, H);
     if (withF) {
-        S::MF::template cols<NX, 0, NT>(K.img + S::OF, K.g, K.xl ? r : 0, frow);
-        S::MF::template column<NX>(K.img + S::OF, K.g, r < NT ? r : 0, fcol);
+        S::MF::template cols<NX, 0, NT>(K.imgF(t), K.g, K.xl ? r : 0, frow);
+        S::MF::template column<NX>(K.imgF(t), K.g, r < NT ? r : 0, fcol);
 #pragma unroll
         for (int c = 0; c < NT; ++c) frow[c] = K.xl ? frow[c] : 0.0;
 #pragma unroll
@@ -252,6 +300,7 @@ __device__ __forceinline__ void stage_rows(const Ctx<C> &K, bool withF, double (
 template <class C> __device__ __forceinline__ void fetch_CF(const Ctx<C> &K, int t)
 {
     using S = Stage<C>;
+    if constexpr (C::WSL) return;
     S::MC::template fetch<C::NT>(K.img, K.Cblk(t), C::NT * C::NT * 8, K.qmax, K.lane);
     if (t < K.T - 1) S::MF::template fetch<C::NX>(K.img + S::OF, K.Fblk(t), C::NX * C::NT * 8, K.qmax, K.lane);
 }
@@ -259,19 +308,38 @@ template <class C> __device__ __forceinline__ void fetch_CF(const Ctx<C> &K, int
 template <class C, bool WITHP> __device__ __forceinline__ void fetch_facF(const Ctx<C> &K, int t)
 {
     using S = Stage<C>;
+    if constexpr (C::WSL) return;
     if (WITHP) S::MP::template fetch<C::NX>(K.img, K.Pblk(t), K.L.total * 8, 3, K.lane);
     S::ML::template fetch<C::NT>(K.img + S::OL, K.Lblk(t), K.L.total * 8, 3, K.lane);
     if (t < K.T - 1) S::MF::template fetch<C::NX>(K.img + S::OF, K.Fblk(t), C::NX * C::NT * 8, K.qmax, K.lane);
 }
-// this lane's row of [Lxu ; Luu] and, on a control lane, 1 / L_jj (kept on the diagonal)
-template <class C> __device__ __forceinline__ double stage_L(const Ctx<C> &K, double (&lrow)[C::NU])
+// this lane's row of [Lxu ; Luu] of knot t and, on a control lane, 1 / L_jj (kept on the diagonal)
+template <class C> __device__ __forceinline__ double stage_L(const Ctx<C> &K, int t, double (&lrow)[C::NU])
 {
     using S = Stage<C>;
-    S::ML::template cols<C::NT, 0, C::NU>(K.img + S::OL, K.g, K.r < C::NT ? K.r : 0, lrow);
+    if constexpr (C::WSL) {
+        const double *o = K.w + K.L.FACL + (t * C::NT + (K.r < C::NT ? K.r : 0)) * C::NU;
+#pragma unroll
+        for (int b = 0; b < C::NU; ++b) lrow[b] = o[b];
+    } else {
+        S::ML::template cols<C::NT, 0, C::NU>(K.img + S::OL, K.g, K.r < C::NT ? K.r : 0, lrow);
+    }
     double rd = 0.0;
 #pragma unroll
     for (int b = 0; b < C::NU; ++b) rd = (K.ul && K.a == b) ? lrow[b] : rd;
     return rd;
+}
+// this lane's row of P_t (state lanes)
+template <class C> __device__ __forceinline__ void stage_P(const Ctx<C> &K, int t, double (&prow)[C::NX])
+{
+    using S = Stage<C>;
+    if constexpr (C::WSL) {
+        const double *o = K.w + K.L.FACP + (t * C::NX + (K.xl ? K.r : 0)) * C::NX;
+#pragma unroll
+        for (int c = 0; c < C::NX; ++c) prow[c] = o[c];
+    } else {
+        S::MP::template cols<C::NX, 0, C::NX>(K.img, K.g, K.xl ? K.r : 0, prow);
+    }
 }
 // the factor rows of one knot out of the registers: H = [P | Lxu] on the state lanes, [. | Luu] on the control lanes
 template <class C> __device__ __forceinline__ void store_fac(const Ctx<C> &K, double *w, int t, const double (&H)[C::NT], double rdj)
@@ -320,7 +388,7 @@ __device__ __forceinline__ bool factor(const Ctx<C> &K0, bool unit, bool clampd)
     for (int t = T - 1; t >= 0; --t) {
         double H[NT], frow[NT], fcol[NX];
         wait_vm();
-        stage_rows<C>(K, t < T - 1, H, frow, fcol);
+        stage_rows<C>(K, t, t < T - 1, H, frow, fcol);
         wait_lds();
         double dn = dd;
         if (t > 0) { dn = load_d(t - 1); fetch_CF<C>(K, t - 1); }
@@ -418,14 +486,14 @@ __device__ __forceinline__ bool factor_fused(const Ctx<C> &K0, double &nx2, doub
         double *w = K.w;
 #pragma unroll
         for (int i = 0; i < V_N; ++i) v[i] = (i == V_SU || i == V_SL) ? 1.0 : 0.0;
-        if (r < NT) { v[V_TAU] = w[L.X + t * NT + r]; v[V_MC] = K.P.mc[((long long)t * K.P.B + K.qp) * NT + r]; }
+        if (r < NT) { v[V_TAU] = w[L.X + t * NT + r]; v[V_MC] = K.cvec(t); }
         if (K.ul) {
             const int iu = t * NU + K.a;
             v[V_SU] = w[L.SU + iu]; v[V_SL] = w[L.SL + iu]; v[V_ZU] = w[L.ZU + iu]; v[V_ZL] = w[L.ZL + iu];
         }
         if (K.xl) {
             v[V_YP] = w[L.Y + (t >= 1 ? t - 1 : T - 1) * NX + r];
-            if (!DYN && t < T - 1) v[V_MF] = K.P.mf[((long long)t * K.P.B + K.qp) * NX + r];
+            if (!DYN && t < T - 1) v[V_MF] = K.fvec(t);
             if (t == 0) v[V_X0] = K.P.mx0[K.qp * NX + r];
         }
     };
@@ -436,7 +504,7 @@ __device__ __forceinline__ bool factor_fused(const Ctx<C> &K0, double &nx2, doub
     for (int t = T - 1; t >= 0; --t) {
         double H[NT], frow[NT], fcol[NX];
         wait_vm();
-        stage_rows<C>(K, t < T - 1, H, frow, fcol);
+        stage_rows<C>(K, t, t < T - 1, H, frow, fcol);
         wait_lds();
         if (t > 0) {
             const Ctx<C> Kt = fresh<C>(K);          // the prefetch addresses are recomputed per knot, not kept
@@ -550,8 +618,8 @@ __device__ __forceinline__ void rhs_load(const Ctx<C> &K, int t, double (&v)[R_N
 #pragma unroll
     for (int i = 0; i < R_N; ++i) v[i] = (i == R_B || i == R_C) ? 1.0 : 0.0;
     if (MODE == INIT) {            // batch.py:60-74: rx = p, rs = 0, rz = -h, ry = -b with d = 1
-        if (NEED_Q && r < NT) v[R_A] = K.P.mc[((long long)t * K.P.B + K.qp) * NT + r];
-        if (NEED_E && K.xl && t < T - 1) v[R_H] = K.P.mf[((long long)t * K.P.B + K.qp) * NX + r];
+        if (NEED_Q && r < NT) v[R_A] = K.cvec(t);
+        if (NEED_E && K.xl && t < T - 1) v[R_H] = K.fvec(t);
     } else if (MODE == AFFINE) {   // rx, rs = z, rz, ry of the iterate
         if (NEED_Q) {
             if (r < NT) v[R_A] = w[L.RX + t * NT + r];
@@ -602,10 +670,10 @@ __device__ __forceinline__ void sweep_back(const Ctx<C> &K0, double musig)
     for (int t = T - 1; t >= 0; --t) {
         double fcol[NX], lcol[NU], prow[NX];
         wait_vm();
-        const double rd = stage_L<C>(K, lcol);
-        if (USE_E) S::MP::template cols<NX, 0, NX>(K.img, K.g, K.xl ? r : 0, prow);
+        const double rd = stage_L<C>(K, t, lcol);
+        if (USE_E) stage_P<C>(K, t, prow);
         if (t < T - 1) {
-            S::MF::template column<NX>(K.img + S::OF, K.g, r < NT ? r : 0, fcol);
+            S::MF::template column<NX>(K.imgF(t), K.g, r < NT ? r : 0, fcol);
 #pragma unroll
             for (int i = 0; i < NX; ++i) fcol[i] = r < NT ? fcol[i] : 0.0;
         }
@@ -691,9 +759,9 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K0, double musig)
     for (int t = 0; t < T; ++t) {
         double lrow[NU], prow[NX], frow[NT];
         wait_vm();
-        const double rd = stage_L<C>(K, lrow);
-        S::MP::template cols<NX, 0, NX>(K.img, K.g, K.xl ? r : 0, prow);
-        if (t < T - 1) S::MF::template cols<NX, 0, NT>(K.img + S::OF, K.g, K.xl ? r : 0, frow);
+        const double rd = stage_L<C>(K, t, lrow);
+        stage_P<C>(K, t, prow);
+        if (t < T - 1) S::MF::template cols<NX, 0, NT>(K.imgF(t), K.g, K.xl ? r : 0, frow);
         wait_lds();
         if (t < T - 1) { load_vec(t + 1, nxt); fetch_facF<C, true>(K, t + 1); }
         {   // the multiplier behind x_t:  dy_{t-1} = P_t dx_t + p_t ;  t = 0:  dy_init = -(P_0 dx_0 + p_0)
@@ -842,12 +910,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
     const Lay L = layout(NX, NU, T);
     // a duplicated (padding) row works on its own copy of the last problem's scratch: rows must not race
     const long long slot = (long long)blockIdx.x * 4 + (lane >> 4);
-    __shared__ __attribute__((aligned(16))) double img[Stage<C>::TOTAL];
+    __shared__ __attribute__((aligned(16))) double lds_img[C::WSL ? 2 : Stage<C>::TOTAL];
+    using S = Stage<C>;
+    double *img = C::WSL ? lds_dyn : lds_img;
     const long long qp0 = (long long)blockIdx.x * 4;
-    Ctx<C> K = {P, P.workspace + slot * (long long)L.total, L, qp, r, T, r < NX, r >= NX && r < NT, live,
+    double *ws0 = C::WSL ? lds_dyn + S::res_ws(T) : P.workspace + qp0 * (long long)L.total;
+    Ctx<C> K = {P, ws0 + (lane >> 4) * (long long)L.total, L, qp, r, T, r < NX, r >= NX && r < NT, live,
                 (r >= NX && r < NT) ? r - NX : 0, 0.0, 0.0,
-                lane, lane >> 4, (int)min(3LL, (long long)P.B - 1 - qp0), qp0, P.workspace + qp0 * (long long)L.total, img};
+                lane, lane >> 4, (int)min(3LL, (long long)P.B - 1 - qp0), qp0, ws0, img,
+                S::res_f(T), lds_dyn + S::res_c(T), lds_dyn + S::res_fv(T)};
     K.uu = P.muu[K.a]; K.ulo = P.mul[K.a];
+    if constexpr (C::WSL) {     // the whole problem into LDS, once
+        S::MC::template fetch_all<NT>(img, K.Cblk(0), (long long)P.B * NT * NT * 8, NT * NT * 8, K.qmax, lane, T);
+        if (T > 1) S::MF::template fetch_all<NX>(img + K.rf, K.Fblk(0), (long long)P.B * NX * NT * 8, NX * NT * 8, K.qmax, lane, T - 1);
+        double *lc = lds_dyn + S::res_c(T), *lf = lds_dyn + S::res_fv(T);
+        for (int i = lane; i < T * 4 * NT; i += 64) {
+            const int t = i / (4 * NT), gq = (i / NT) % 4, rr = i % NT;
+            lc[i] = P.mc[((long long)t * P.B + qp0 + min(gq, K.qmax)) * NT + rr];
+        }
+        for (int i = lane; i < (T - 1) * 4 * NX; i += 64) {
+            const int t = i / (4 * NX), gq = (i / NX) % 4, rr = i % NX;
+            lf[i] = P.mf[((long long)t * P.B + qp0 + min(gq, K.qmax)) * NX + rr];
+        }
+        wait_vm();
+    }
     double *w = K.w;
     const int nineq = 2 * T * NU;
     int status = DQP_STATUS_OK;
@@ -953,7 +1039,8 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P, int T)
     const long long qp0 = (long long)blockIdx.x * 4;
     Ctx<C> K = {P, P.workspace + slot * (long long)L.total, L, qp, r, T, r < NX, r >= NX && r < NT, live,
                 (r >= NX && r < NT) ? r - NX : 0, 0.0, 0.0,
-                lane, lane >> 4, (int)min(3LL, (long long)P.B - 1 - qp0), qp0, P.workspace + qp0 * (long long)L.total, img};
+                lane, lane >> 4, (int)min(3LL, (long long)P.B - 1 - qp0), qp0, P.workspace + qp0 * (long long)L.total, img,
+                0, nullptr, nullptr};
     double *w = K.w;
     const int nz = T * NT, neq = T * NX, hm = T * NU;
     for (int i = r; i < hm; i += 16) {
@@ -1026,10 +1113,10 @@ __global__ __launch_bounds__(64) void finish_kernel(KParams P, int T, int nx, in
     }
 }
 
-template <class C, class Kern> int launch(Kern kernel, const KParams &P, int T, void *stream)
+template <class C, class Kern> int launch(Kern kernel, const KParams &P, int T, void *stream, size_t lds = 0)
 {
     const int blocks = (P.B + 3) / 4;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, P, T);
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P, T);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
@@ -1058,13 +1145,22 @@ long long ric_workspace_doubles(int n, int m, int T)
 int ric_forward(const KParams &P, void *stream)
 {
     // the true-dynamics residual of a registered model is its own instantiation: the model's registers
-    // (an RK4 step of the quadrotor) would otherwise be spilled around on the linear path too
+    // (an RK4 step of the quadrotor) would otherwise be spilled around on the linear path too.
+    // Workspace in LDS (Cfg<., ., true>) where four of them fit beside the stage without starving the CU
+    // of wavefronts: up to 40 KB per wavefront, or up to 64 KB while the batch is at most two per CU.
 #define X(a, b)                                                                                                       \
     if (P.mn == a && P.mm == b) {                                                                                     \
-        using Cf = ric::Cfg<a, b>;                                                                                    \
-        if constexpr (ric::has_model<Cf>())                                                                           \
-            if (P.dynId) return ric::launch<Cf>(ric::forward_kernel<Cf, true>, P, P.mT, stream);                      \
-        return P.dynId ? 1 : ric::launch<Cf>(ric::forward_kernel<Cf, false>, P, P.mT, stream);                        \
+        using Cg = ric::Cfg<a, b>;                                                                                    \
+        using Cl = ric::Cfg<a, b, true>;                                                                              \
+        const size_t lds = (ric::Stage<Cl>::res_ws(P.mT) + 4 * (size_t)ric::layout(a, b, P.mT).total) * sizeof(double); \
+        const bool wsl = !(P.flags & DQP_FLAG_RIC_GLOBAL_WS) && (lds <= 40 * 1024 || (lds <= 64 * 1024 && (P.B + 3) / 4 <= 512)); \
+        if constexpr (ric::has_model<Cg>())                                                                           \
+            if (P.dynId)                                                                                              \
+                return wsl ? ric::launch<Cl>(ric::forward_kernel<Cl, true>, P, P.mT, stream, lds)                     \
+                           : ric::launch<Cg>(ric::forward_kernel<Cg, true>, P, P.mT, stream);                         \
+        if (P.dynId) return 1;                                                                                        \
+        return wsl ? ric::launch<Cl>(ric::forward_kernel<Cl, false>, P, P.mT, stream, lds)                            \
+                   : ric::launch<Cg>(ric::forward_kernel<Cg, false>, P, P.mT, stream);                                \
     }
     DQP_RIC_SIZES
 #undef X

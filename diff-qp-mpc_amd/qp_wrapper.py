@@ -76,6 +76,11 @@ def _stream(dev):
     return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+# OR-ed into dqp_opts.flags of dqp_mpc_qp_forward (tests: DQP_FLAG_RIC_GLOBAL_WS pins the stage-wise kernels'
+# workspace to the caller's buffer where the default keeps it in LDS)
+EXTRA_FLAGS = 0
+
+
 class _AssembleDenseQP(Function):
     """(C, c, F, f, x0) -> (Q, p, G, h, A, b) on the device (qp_wrapper.py:638-679)."""
 
@@ -159,7 +164,7 @@ class _MPCQP(Function):
         # dyn_res closure, qp_wrapper.py:309,316); F, f stay the linearisation the Newton steps use
         dims = _lib.dqp_mpc_dims(B, n_state, n_ctrl, T, 1, dyn.id if dyn is not None else 0)
         batch = qpmod.TERMINATION == "batch"
-        opts = _lib.dqp_opts(1e-12, qpmod.STALL_TOL, 20, 3, _lib.DQP_FLAG_BATCH_TERMINATION if batch else 0, 0)
+        opts = _lib.dqp_opts(1e-12, qpmod.STALL_TOL, 20, 3, (_lib.DQP_FLAG_BATCH_TERMINATION if batch else 0) | EXTRA_FLAGS, 0)
         if dyn is not None:
             opts.dyn_dt = dyn.dt
         kw = dict(dtype=torch.float64, device=dev)

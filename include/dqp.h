@@ -78,6 +78,9 @@ enum {
                                       the dominant launch on its own                                */
 #define DQP_FLAG_NO_NULLSPACE 4u   /* forward: keep the equality rows in the iteration even when a
                                       workspace is given (the kernel used without one)       */
+#define DQP_FLAG_RIC_GLOBAL_WS 64u  /* testing: dqp_mpc_qp_forward's stage-wise kernels keep their iterates
+                                      and factors in the caller's workspace even where they would
+                                      fit in LDS (the path long horizons take)                  */
 
 typedef struct dqp_dims {
     int32_t nbatch;

@@ -340,3 +340,25 @@ def test_stagewise_more_size_pairs(n, m, T, B):
     nt = n + m
     dc = np.stack([og["dp"][:, t * nt:(t + 1) * nt] for t in range(T)])
     np.testing.assert_allclose(grads[1], dc, err_msg="dc", **GT)
+
+
+@pytest.mark.parametrize("n,m,T,B", [(3, 1, 10, 9), (4, 2, 6, 130), (6, 1, 5, 7), (12, 4, 4, 6), (3, 3, 8, 5)])
+def test_stagewise_lds_resident_equals_global_workspace(n, m, T, B):
+    """Short horizons keep the whole problem (C, F, c, f, iterates, factors) in LDS; DQP_FLAG_RIC_GLOBAL_WS pins the
+    same sizes to the caller's workspace (the path long horizons take, LDS-DMA prefetch of every knot).  Same
+    arithmetic in the same order: identical outputs, and both against the CPU oracle."""
+    from diff_qp_mpc_amd import _lib, qp_wrapper
+    data = problem(n, m, T, B, seed=5 * n + T)
+    tau_l, grads_l, w = run_fused(n, m, T, data)
+    old = qp_wrapper.EXTRA_FLAGS
+    qp_wrapper.EXTRA_FLAGS = _lib.DQP_FLAG_RIC_GLOBAL_WS
+    try:
+        tau_g, grads_g, _ = run_fused(n, m, T, data)
+    finally:
+        qp_wrapper.EXTRA_FLAGS = old
+    np.testing.assert_array_equal(tau_l, tau_g)
+    for a, b in zip(grads_l, grads_g):
+        np.testing.assert_array_equal(a, b)
+    Q, p, G, h, A, b = assemble(*data)
+    o = oracle.dense_forward(Q, p, G, h, A, b)
+    np.testing.assert_allclose(tau_l.reshape(B, -1), o["zhat"], **ZT)
