@@ -28,9 +28,10 @@
 extern "C" {
 #endif
 
-#define DQP_VERSION 211 /* 0.2.1x: dqp_mpc_qp_backward takes C and F, dqp_mpc_dims.dyn_id, dqp_mpc_qp_termination_bytes,
+#define DQP_VERSION 212 /* 0.2.1x: dqp_mpc_qp_backward takes C and F, dqp_mpc_dims.dyn_id, dqp_mpc_qp_termination_bytes,
                            dqp_term_local_masks + dqp_qp_forward_finish,
-                           dqp_al_newton_solve_bytes(dims, banded) */
+                           dqp_al_newton_solve_bytes(dims, banded); 212: DQP_FLAG_RIC_GLOBAL_WS, smaller
+                           dqp_mpc_qp_workspace_bytes of the stage-wise kernels */
 #define DQP_MAX_DIM 64
 
 enum {
