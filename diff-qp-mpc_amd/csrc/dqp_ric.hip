@@ -379,7 +379,7 @@ __device__ __forceinline__ bool factor(const Ctx<C> &K0, bool unit, bool clampd)
             const int iu = t * NU + K.a;
             double su = w[L.SU + iu], sl = w[L.SL + iu], zu = w[L.ZU + iu], zl = w[L.ZL + iu];
             if (clampd) { su = fmax(su, 1e-8); sl = fmax(sl, 1e-8); zu = fmax(zu, 1e-8); zl = fmax(zl, 1e-8); }
-            dd = zu / su + zl / sl;
+            dd = zu * frcp(su) + zl * frcp(sl);
         }
         return dd;
     };
@@ -526,7 +526,7 @@ __device__ __forceinline__ bool factor_fused(const Ctx<C> &K0, double &nx2, doub
             w[L.RZU + iu] = rzu; w[L.RZL + iu] = rzl;
             nz2 = fma(rzu, rzu, fma(rzl, rzl, nz2));
             sz = fma(su, zu, fma(sl, zl, sz));
-            const double du_ = zu / su, dl_ = zl / sl;
+            const double du_ = zu * frcp(su), dl_ = zl * frcp(sl);
             q = -((zu - du_ * rzu) - (zl - dl_ * rzl));
 #pragma unroll
             for (int c = 0; c < NT; ++c) H[c] += (r == c) ? du_ + dl_ : 0.0;
@@ -644,8 +644,8 @@ template <class C, int MODE>
 __device__ __forceinline__ double rhs_q(const Ctx<C> &K, const double (&v)[R_N], double musig)
 {
     if (MODE == INIT) return v[R_A] - (K.ul ? K.uu + K.ulo : 0.0);
-    if (MODE == AFFINE) return K.ul ? v[R_A] - ((v[R_D] - v[R_D] / v[R_B] * v[R_F]) - (v[R_E] - v[R_E] / v[R_C] * v[R_G])) : v[R_A];
-    if (MODE == CORRECTOR) return K.ul ? -((-musig + v[R_D] * v[R_E]) / v[R_B] - (-musig + v[R_F] * v[R_G]) / v[R_C]) : 0.0;
+    if (MODE == AFFINE) return K.ul ? v[R_A] - ((v[R_D] - v[R_D] * frcp(v[R_B]) * v[R_F]) - (v[R_E] - v[R_E] * frcp(v[R_C]) * v[R_G])) : v[R_A];
+    if (MODE == CORRECTOR) return K.ul ? -((-musig + v[R_D] * v[R_E]) * frcp(v[R_B]) - (-musig + v[R_F] * v[R_G]) * frcp(v[R_C])) : 0.0;
     return v[R_A];
 }
 
@@ -795,22 +795,25 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K0, double musig)
             } else {
                 const double su = cur[V_SU], sl = cur[V_SL], zu = cur[V_ZU], zl = cur[V_ZL];
                 double dsu, dsl, dzu, dzl;
+                // reciprocals (hardware estimate + two Newton steps, as the dense kernels' ratio test) instead
+                // of IEEE divisions: ten of those per knot were most of this sweep's instructions
+                const double isu = frcp(su), isl = frcp(sl);
                 if (MODE == AFFINE) {
                     dsu = -cur[V_A] - dtau; dsl = -cur[V_B] + dtau;
-                    dzu = -zu - zu / su * dsu;   dzl = -zl - zl / sl * dsl;
+                    dzu = -zu - zu * isu * dsu;   dzl = -zl - zl * isl * dsl;
                 } else {
                     const double asu = cur[V_A], asl = cur[V_B], azu = cur[V_C], azl = cur[V_D];
-                    const double rsu = (-musig + asu * azu) / su, rsl = (-musig + asl * azl) / sl;
+                    const double rsu = (-musig + asu * azu) * isu, rsl = (-musig + asl * azl) * isl;
                     const double csu = -dtau, csl = dtau;
                     dsu = asu + csu; dsl = asl + csl;
-                    dzu = azu + (-rsu - zu / su * csu); dzl = azl + (-rsl - zl / sl * csl);
+                    dzu = azu + (-rsu - zu * isu * csu); dzl = azl + (-rsl - zl * isl * csl);
                 }
                 w[L.DSU + iu] = dsu; w[L.DSL + iu] = dsl; w[L.DZU + iu] = dzu; w[L.DZL + iu] = dzl;
                 // get_step (batch.py:206-214, with batch_LU's dv == 0 guard): a = -v/dv where dv < 0
-                ratio = fmin(ratio, dsu < 0.0 ? -su / dsu : INFINITY);
-                ratio = fmin(ratio, dsl < 0.0 ? -sl / dsl : INFINITY);
-                ratio = fmin(ratio, dzu < 0.0 ? -zu / dzu : INFINITY);
-                ratio = fmin(ratio, dzl < 0.0 ? -zl / dzl : INFINITY);
+                ratio = fmin(ratio, dsu < 0.0 ? -su * frcp(dsu) : INFINITY);
+                ratio = fmin(ratio, dsl < 0.0 ? -sl * frcp(dsl) : INFINITY);
+                ratio = fmin(ratio, dzu < 0.0 ? -zu * frcp(dzu) : INFINITY);
+                ratio = fmin(ratio, dzl < 0.0 ? -zl * frcp(dzl) : INFINITY);
             }
         }
         if (t < T - 1) {
