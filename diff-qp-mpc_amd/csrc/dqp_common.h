@@ -28,7 +28,7 @@ struct KParams {
     unsigned flags;
     // batch-coupled termination (DQP_FLAG_BATCH_TERMINATION, dqp_term.hip)
     double *hist;          // pass 1: (B, histIters, 2) = (resid, mu) per iteration, or NULL
-    const int32_t *cap;    // pass 2: cap[0] = iteration cap, cap[TERM_HDR + qp] = re-solve this QP
+    const int32_t *cap;    // pass 2: cap[0] = iteration cap I*, cap[TERM_HDR + qp] = iteration of this QP's best iterate
     int histIters;
     // true-dynamics equality residual (dqp_opts.dyn_*): registered model evaluated per iteration
     int dynId, dynT, dynN, dynM;
@@ -45,7 +45,7 @@ struct KParams {
     const double *histIn;
 };
 
-constexpr int TERM_HDR = 8;   // int32 header words in front of the redo list
+constexpr int TERM_HDR = 8;   // int32 header words in front of the per-problem best-iteration list
 
 // Termination buffer (dqp_termination_bytes), see dqp_term.hip: hist [histIters][B] x (resid, mu),
 // then TERM_ACC_BYTES of accumulators + header, then the redo list.
@@ -77,7 +77,10 @@ __device__ __forceinline__ void term_zero_acc(const KParams &P)
     }
 }
 
-// batch rule replay + redo list (dqp_term.hip); 0 on success
+// pass 2: a problem is taken back iff its best iterate of pass 1 came at an iteration the reference never ran
+__device__ __forceinline__ bool term_flagged(const KParams &P, long long qp) { return P.cap[TERM_HDR + qp] >= P.cap[0]; }
+
+// batch rule replay (dqp_term.hip); 0 on success
 size_t term_bytes(int B, int maxIter, int snapDim);
 int term_decide(const KParams &P, void *term, void *stream);
 int term_local_masks(const KParams &P, void *term, unsigned long long *masks, void *stream);

@@ -492,7 +492,7 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
     int maxIter = P.maxIter;
     const bool batch = (P.flags & DQP_FLAG_BATCH_TERMINATION) != 0;
     if (P.cap) {        // pass 2 of the batch rule: only the listed QPs, up to the reference's stop
-        if (P.cap[TERM_HDR + qp] == 0) return;
+        if (!term_flagged(P, qp)) return;
         maxIter = min(maxIter, P.cap[0]);
     }
     const int status = qp_setup(P, S, qp, lane, rdq, rd1);

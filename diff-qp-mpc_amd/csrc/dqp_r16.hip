@@ -276,7 +276,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     const bool batch = (P.flags & DQP_FLAG_BATCH_TERMINATION) != 0;
     if (P.cap) {        // pass 2 of the batch rule: only the listed QPs, up to the reference's stop
         maxIter = min(maxIter, P.cap[0]);
-        live = live && P.cap[TERM_HDR + qp] != 0;
+        live = live && term_flagged(P, qp);
         if (__builtin_amdgcn_ballot_w64(live) == 0) return;
     }
     double *lds = sm + qrow * C::ldsQPpad;

@@ -906,7 +906,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
     const bool batch = (P.flags & DQP_FLAG_BATCH_TERMINATION) != 0;
     if (P.cap) {        // pass 2 of the batch rule: only the listed QPs, up to the reference's stop
         maxIter = min(maxIter, P.cap[0]);
-        live = live && P.cap[TERM_HDR + qp] != 0;
+        live = live && term_flagged(P, qp);
         if (__builtin_amdgcn_ballot_w64(live) == 0) return;
     }
     term_zero_acc(P);
@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(64) void backward_kernel(KParams P, int T)
 __global__ __launch_bounds__(64) void finish_kernel(KParams P, int T, int nx, int nu)
 {
     const long long qp = blockIdx.x;
-    if (P.cap[TERM_HDR + qp] == 0) return;
+    if (!term_flagged(P, qp)) return;
     const int cap = min(P.maxIter, P.cap[0]);
     const double2 *h = reinterpret_cast<const double2 *>(P.histIn) + qp;
     double best = h[0].x;

@@ -13,8 +13,8 @@
 //
 // Buffer layout (dqp_termination_bytes): hist (maxIter, B) x {resid, mu} doubles | accumulators:
 // three u64 masks (improved, notbelow, notabove: one bit per iteration) | int32 header[TERM_HDR]
-// (header[0] = I*, header[1] = number of problems to redo, header[2] = block arrival counter) then
-// int32 redo[B] (the scan stores the problem's best iteration there, its last block the flag), then
+// (header[0] = I*, header[2] = block arrival counter) then int32 best[B] (the iteration of each problem's
+// best iterate over all of pass 1: pass 2 takes a problem back iff best[qp] >= I*), then
 // (16-byte aligned) the iterate snapshots [maxIter][B][snapDim] of the null-space kernels: every
 // improving iterate of pass 1, so that pass 2 is an epilogue (r16n::finish_kernel), not a re-solve.
 // Pass 1 zeroes accumulators + header itself (term_zero_acc), so a forward call is three launches.
@@ -44,101 +44,81 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v)
     return v;
 }
 
-// One thread per problem walks its history (best-so-far, the iteration it was found at) and
-// collects its three masks; one OR-reduction per wavefront, one atomicOr per block.  The last block
-// to finish replays the reference's rule on the masks and writes I* and the redo flags
-// (hdr[0], hdr[1], hdr[TERM_HDR + qp]; hdr[2] is the arrival counter).
-__global__ __launch_bounds__(256) void term_scan_kernel(const double2 *hist, Acc *acc, int32_t *hdr,
-                                                        int B, int maxIter, int notImprovedLim, double eps,
-                                                        int decide)
+// the reference's rule on the batch-wide masks -> the iteration count it stops at
+__device__ __forceinline__ int rule_stop(unsigned long long ai, unsigned long long anb, unsigned long long ana, int maxIter,
+                                         int notImprovedLim)
 {
-    __shared__ unsigned long long s_m[3][4];
-    __shared__ int s_last, s_istop;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const long long qp = (long long)blockIdx.x * blockDim.x + tid;
+    int nNot = 0;
+    for (int it = 0; it < maxIter; ++it) {
+        if (it == 0 || ((ai >> it) & 1ull)) nNot = 0;
+        else nNot += 1;
+        if (nNot == notImprovedLim || !((anb >> it) & 1ull) || !((ana >> it) & 1ull)) return it + 1;
+    }
+    return maxIter;
+}
+
+// One thread per problem walks its history (best-so-far, the iteration it was found at: stored in
+// hdr[TERM_HDR + qp], pass 2 compares it with I*) and collects its three masks; one OR-reduction per
+// wavefront, one atomicOr per block.  The last block to finish replays the reference's rule on the masks
+// and writes I* (hdr[0]; hdr[2] is the arrival counter).  The history is read eight iterations at a time
+// (independent loads), and nothing here is O(B) on one thread: the first version's last block turned the
+// best-iteration list into flags in a loop of dependent L2 round trips, two thirds of its 15 us.
+__global__ __launch_bounds__(64) void term_scan_kernel(const double2 *hist, Acc *acc, int32_t *hdr,
+                                                       int B, int maxIter, int notImprovedLim, double eps,
+                                                       int decide)
+{
+    const int lane = threadIdx.x;
+    const long long qp = (long long)blockIdx.x * blockDim.x + lane;
     const bool live = qp < B;
-    int32_t *argbest = hdr + TERM_HDR;
     unsigned long long imp = 0ull, nb = 0ull, na = 0ull;
     if (live) {
         const double2 *h = hist + qp;
         double best = 0.0;
         int arg = 0;
-        for (int it = 0; it < maxIter; ++it) {
-            const double2 v = h[(long long)it * B];
-            if (it == 0) best = v.x;                                   // batch.py:120-126
-            else if (v.x < best) { best = v.x; arg = it; imp |= 1ull << it; }
-            if (!(best < eps)) nb |= 1ull << it;
-            if (!(v.y > 1e32)) na |= 1ull << it;
+        for (int it0 = 0; it0 < maxIter; it0 += 8) {
+            double2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = h[(long long)min(it0 + k, maxIter - 1) * B];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int it = it0 + k;
+                if (it < maxIter) {
+                    if (it == 0) best = v[k].x;                                   // batch.py:120-126
+                    else if (v[k].x < best) { best = v[k].x; arg = it; imp |= 1ull << it; }
+                    if (!(best < eps)) nb |= 1ull << it;
+                    if (!(v[k].y > 1e32)) na |= 1ull << it;
+                }
+            }
         }
-        argbest[qp] = arg;
+        hdr[TERM_HDR + qp] = arg;
     }
     imp = wave_or_u64(imp); nb = wave_or_u64(nb); na = wave_or_u64(na);
-    if (lane == 0) { s_m[0][wave] = imp; s_m[1][wave] = nb; s_m[2][wave] = na; }
-    __syncthreads();
-    if (tid < 3) {
-        const unsigned long long m = s_m[tid][0] | s_m[tid][1] | s_m[tid][2] | s_m[tid][3];
-        unsigned long long *dst = tid == 0 ? &acc->improved : (tid == 1 ? &acc->notbelow : &acc->notabove);
+    if (lane < 3) {
+        const unsigned long long m = lane == 0 ? imp : (lane == 1 ? nb : na);
+        unsigned long long *dst = lane == 0 ? &acc->improved : (lane == 1 ? &acc->notbelow : &acc->notabove);
         if (m) atomicOr(dst, m);
     }
     if (!decide) return;            // multi-device form: the masks are combined across devices first
     // ---- last block: the rule itself
     __threadfence();
-    __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(&hdr[2], 1) == (int)gridDim.x - 1);
-    __syncthreads();
-    if (!s_last) return;
+    int last = 0;
+    if (lane == 0) last = (atomicAdd(&hdr[2], 1) == (int)gridDim.x - 1);
+    last = __shfl(last, 0, 64);
+    if (!last) return;
     __threadfence();
-    if (tid == 0) {
+    if (lane == 0) {
         const unsigned long long ai = __hip_atomic_load(&acc->improved, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long anb = __hip_atomic_load(&acc->notbelow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long ana = __hip_atomic_load(&acc->notabove, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int istop = maxIter, nNot = 0;
-        for (int it = 0; it < maxIter; ++it) {
-            if (it == 0 || ((ai >> it) & 1ull)) nNot = 0;
-            else nNot += 1;
-            if (nNot == notImprovedLim || !((anb >> it) & 1ull) || !((ana >> it) & 1ull)) { istop = it + 1; break; }
-        }
-        s_istop = istop;
-        hdr[0] = istop;
+        hdr[0] = rule_stop(ai, anb, ana, maxIter, notImprovedLim);
     }
-    __syncthreads();
-    const int istop = s_istop;
-    int nredo = 0;
-    for (long long q = tid; q < B; q += blockDim.x) {
-        const int redo = __hip_atomic_load(&argbest[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= istop ? 1 : 0;
-        argbest[q] = redo;
-        nredo += redo;
-    }
-    if (nredo) atomicAdd(&hdr[1], nredo);
 }
 
-// The rule on given masks (multi-device form: the OR of every shard's masks), then this shard's redo
-// flags; one workgroup.
-__global__ __launch_bounds__(256) void term_decide_kernel(const unsigned long long *masks, int32_t *hdr, int B,
-                                                          int maxIter, int notImprovedLim)
+// The rule on given masks (multi-device form: the OR of every shard's masks)
+__global__ __launch_bounds__(64) void term_decide_kernel(const unsigned long long *masks, int32_t *hdr, int maxIter,
+                                                         int notImprovedLim)
 {
-    __shared__ int s_istop;
-    int32_t *argbest = hdr + TERM_HDR;
-    if (threadIdx.x == 0) {
-        const unsigned long long ai = masks[0], anb = masks[1], ana = masks[2];
-        int istop = maxIter, nNot = 0;
-        for (int it = 0; it < maxIter; ++it) {
-            if (it == 0 || ((ai >> it) & 1ull)) nNot = 0;
-            else nNot += 1;
-            if (nNot == notImprovedLim || !((anb >> it) & 1ull) || !((ana >> it) & 1ull)) { istop = it + 1; break; }
-        }
-        s_istop = istop;
-        hdr[0] = istop;
-    }
-    __syncthreads();
-    const int istop = s_istop;
-    int nredo = 0;
-    for (long long q = threadIdx.x; q < B; q += blockDim.x) {
-        const int redo = argbest[q] >= istop ? 1 : 0;
-        argbest[q] = redo;
-        nredo += redo;
-    }
-    if (nredo) atomicAdd(&hdr[1], nredo);
+    if (threadIdx.x == 0) hdr[0] = rule_stop(masks[0], masks[1], masks[2], maxIter, notImprovedLim);
 }
 
 inline Acc *acc_of(void *term, int B, int maxIter) { return (Acc *)((char *)term + hist_bytes(B, maxIter)); }
@@ -176,8 +156,8 @@ void term_bind_pass2(KParams &P, void *term)
 
 int term_decide(const KParams &P, void *term, void *stream)
 {
-    const int blocks = (P.B + 255) / 256;
-    hipLaunchKernelGGL(term_scan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    const int blocks = (P.B + 63) / 64;
+    hipLaunchKernelGGL(term_scan_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream,
                        (const double2 *)term, acc_of(term, P.B, P.maxIter), hdr_of(term, P.B, P.maxIter),
                        P.B, P.maxIter, P.notImprovedLim, P.eps, 1);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
@@ -186,8 +166,8 @@ int term_decide(const KParams &P, void *term, void *stream)
 // multi-device form, step 1: this shard's three iteration masks -> masks[3] (device memory)
 int term_local_masks(const KParams &P, void *term, unsigned long long *masks, void *stream)
 {
-    const int blocks = (P.B + 255) / 256;
-    hipLaunchKernelGGL(term_scan_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+    const int blocks = (P.B + 63) / 64;
+    hipLaunchKernelGGL(term_scan_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream,
                        (const double2 *)term, acc_of(term, P.B, P.maxIter), hdr_of(term, P.B, P.maxIter),
                        P.B, P.maxIter, P.notImprovedLim, P.eps, 0);
     if (hipMemcpyAsync(masks, acc_of(term, P.B, P.maxIter), 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
@@ -196,11 +176,11 @@ int term_local_masks(const KParams &P, void *term, unsigned long long *masks, vo
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
-// multi-device form, step 2: the rule on the combined masks, this shard's redo flags
+// multi-device form, step 2: the rule on the combined masks -> I* of this shard's header
 int term_decide_global(const KParams &P, void *term, const unsigned long long *masks, void *stream)
 {
-    hipLaunchKernelGGL(term_decide_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, masks,
-                       hdr_of(term, P.B, P.maxIter), P.B, P.maxIter, P.notImprovedLim);
+    hipLaunchKernelGGL(term_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, masks,
+                       hdr_of(term, P.B, P.maxIter), P.maxIter, P.notImprovedLim);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
