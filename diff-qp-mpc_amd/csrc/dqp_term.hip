@@ -60,9 +60,10 @@ __device__ __forceinline__ int rule_stop(unsigned long long ai, unsigned long lo
 // One thread per problem walks its history (best-so-far, the iteration it was found at: stored in
 // hdr[TERM_HDR + qp], pass 2 compares it with I*) and collects its three masks; one OR-reduction per
 // wavefront, one atomicOr per block.  The last block to finish replays the reference's rule on the masks
-// and writes I* (hdr[0]; hdr[2] is the arrival counter).  The history is read eight iterations at a time
-// (independent loads), and nothing here is O(B) on one thread: the first version's last block turned the
+// and writes I* (hdr[0]; hdr[2] is the arrival counter).  The history is read SCAN_CHUNK iterations at a time
+// (independent loads: the default max_iter = 20 is one round trip), and nothing here is O(B) on one thread: the first version's last block turned the
 // best-iteration list into flags in a loop of dependent L2 round trips, two thirds of its 15 us.
+constexpr int SCAN_CHUNK = 32;
 __global__ __launch_bounds__(64) void term_scan_kernel(const double2 *hist, Acc *acc, int32_t *hdr,
                                                        int B, int maxIter, int notImprovedLim, double eps,
                                                        int decide)
@@ -75,12 +76,12 @@ __global__ __launch_bounds__(64) void term_scan_kernel(const double2 *hist, Acc 
         const double2 *h = hist + qp;
         double best = 0.0;
         int arg = 0;
-        for (int it0 = 0; it0 < maxIter; it0 += 8) {
-            double2 v[8];
+        for (int it0 = 0; it0 < maxIter; it0 += SCAN_CHUNK) {
+            double2 v[SCAN_CHUNK];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = h[(long long)min(it0 + k, maxIter - 1) * B];
+            for (int k = 0; k < SCAN_CHUNK; ++k) v[k] = h[(long long)min(it0 + k, maxIter - 1) * B];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < SCAN_CHUNK; ++k) {
                 const int it = it0 + k;
                 if (it < maxIter) {
                     if (it == 0) best = v[k].x;                                   // batch.py:120-126
