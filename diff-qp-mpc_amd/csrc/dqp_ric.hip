@@ -636,6 +636,7 @@ __device__ __forceinline__ void rhs_load(const Ctx<C> &K, int t, double (&v)[R_N
             v[R_B] = w[L.SU + iu]; v[R_C] = w[L.SL + iu];
             v[R_D] = w[L.DSU + iu]; v[R_E] = w[L.DZU + iu]; v[R_F] = w[L.DSL + iu]; v[R_G] = w[L.DZL + iu];
         }
+        if (NEED_Q && K.xl) v[R_A] = w[L.PV + t * NX + r];       // the affine solve's p_t: see sweep_back
     } else {                       // ADJOINT: rx = dl/dzhat (qp.py:136-141)
         if (NEED_Q && r < NT) v[R_A] = K.P.gin[(K.qp * T + t) * NT + r];            // dl/dtau is (B, T, nt) like tau
     }
@@ -698,7 +699,10 @@ __device__ __forceinline__ void sweep_back(const Ctx<C> &K0, double musig)
             const double lij = (r < NT && (r < NX || r > j)) ? lcol[j - NX] : 0.0;
             h = (r == j) ? hj : fma(-lij, hj, h);
         }
-        if (K.xl) w[L.PV + t * NX + r] = h;
+        // the multipliers are linear in the right-hand side and only their sum over the affine and the corrector
+        // solve is used (the step of y): the corrector leaves p_aff + p_cor, and the forward sweeps multiply
+        // P_t once, by the summed dx (no P_t in the affine sweep: a quarter of the factor reads)
+        if (K.xl) w[L.PV + t * NX + r] = (MODE == CORRECTOR) ? h + cur[R_A] : h;
         if (K.ul) w[L.YB + t * NU + K.a] = h;
         pn = K.xl ? h : 0.0;
         if (USE_E) {
@@ -725,7 +729,7 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K0, double musig)
     double ratio = INFINITY;
     // the knot's vectors: p_t, Luu^-1 h_u, e_t, the constraint rows of the knot's control, and in the
     // corrector the affine step they are added to
-    enum { V_PV, V_YB, V_E, V_SU, V_SL, V_ZU, V_ZL, V_A, V_B, V_C, V_D, V_DXO, V_DYO, V_N };
+    enum { V_PV, V_YB, V_E, V_SU, V_SL, V_ZU, V_ZL, V_A, V_B, V_C, V_D, V_DXO, V_N };
     auto load_vec = [&](int t, double (&v)[V_N]) {
 #pragma unroll
         for (int i = 0; i < V_N; ++i) v[i] = (i == V_SU || i == V_SL) ? 1.0 : 0.0;
@@ -736,7 +740,6 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K0, double musig)
                 rhs_load<C, MODE, false, true>(K, t, rh);
                 v[V_E] = rh[R_H];
             }
-            if (MODE == CORRECTOR) v[V_DYO] = w[L.DY + (t >= 1 ? t - 1 : T - 1) * NX + r];
         }
         if (MODE == CORRECTOR && r < NT) v[V_DXO] = w[L.DX + t * NT + r];
         if (K.ul) {
@@ -754,22 +757,24 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K0, double musig)
         else if (MODE == AFFINE) dx = -w[L.RY + (T - 1) * NX + r];
     }
     double cur[V_N], nxt[V_N];
+    constexpr bool WITHP = (MODE != AFFINE);        // dy comes out of the corrector sweep for both solves
     load_vec(0, cur);
-    fetch_facF<C, true>(K, 0);
+    fetch_facF<C, WITHP>(K, 0);
     for (int t = 0; t < T; ++t) {
         double lrow[NU], prow[NX], frow[NT];
         wait_vm();
         const double rd = stage_L<C>(K, t, lrow);
-        stage_P<C>(K, t, prow);
+        if (WITHP) stage_P<C>(K, t, prow);
         if (t < T - 1) S::MF::template cols<NX, 0, NT>(K.imgF(t), K.g, K.xl ? r : 0, frow);
         wait_lds();
-        if (t < T - 1) { load_vec(t + 1, nxt); fetch_facF<C, true>(K, t + 1); }
-        {   // the multiplier behind x_t:  dy_{t-1} = P_t dx_t + p_t ;  t = 0:  dy_init = -(P_0 dx_0 + p_0)
+        if (t < T - 1) { load_vec(t + 1, nxt); fetch_facF<C, WITHP>(K, t + 1); }
+        if (WITHP) {   // the multiplier behind x_t:  dy_{t-1} = P_t dx_t + p_t ;  t = 0:  dy_init = -(P_0 dx_0 + p_0)
+            const double dxs = (MODE == CORRECTOR) ? dx + (K.xl ? cur[V_DXO] : 0.0) : dx;        // affine + corrector
             double v = cur[V_PV];
 #pragma unroll
-            for (int c = 0; c < NX; ++c) v = fma(K.xl ? prow[c] : 0.0, rb(dx, c), v);
+            for (int c = 0; c < NX; ++c) v = fma(K.xl ? prow[c] : 0.0, rb(dxs, c), v);
             if (t == 0) v = -v;
-            if (K.xl) w[L.DY + (t >= 1 ? t - 1 : T - 1) * NX + r] = (MODE == CORRECTOR) ? cur[V_DYO] + v : v;
+            if (K.xl) w[L.DY + (t >= 1 ? t - 1 : T - 1) * NX + r] = v;
         }
 #pragma unroll
         for (int b = 0; b < NU; ++b) lrow[b] = r < NT ? lrow[b] : 0.0;
