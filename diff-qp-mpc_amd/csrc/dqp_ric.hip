@@ -25,7 +25,8 @@
 // Layout: one QP per 16-lane DPP row (n + m <= 16: a knot is one distributed vector, a stage matrix
 // one row per lane), four QPs per wavefront, iterates / directions / per-knot factors streamed through
 // a caller workspace (dqp_mpc_qp_workspace_bytes) -- the kernel is HBM-stream bound by C, F and the
-// factors (~40 k doubles per QP and iteration at config 4).
+// factors (~60 k doubles per QP and iteration at config 4), so every knot's matrices are prefetched one
+// knot ahead by LDS-DMA (Stage<C>); short horizons run entirely out of LDS (Cfg<n, m, true>).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -51,7 +52,7 @@ template <int NX_, int NU_, bool WSL_ = false> struct Cfg {
 // per-QP workspace (doubles); everything knot-major
 struct Lay {
     int X, Y, SU, SL, ZU, ZL;            // iterate
-    int RX, RY, RZU, RZL;                // residuals of the iterate
+    int RY, RZU, RZL;                    // residuals of the iterate the affine forward sweep reads (rx is consumed where it is formed)
     int DX, DY, DSU, DSL, DZU, DZL;      // step (affine, then affine + corrector)
     int BX, BY, BSU, BSL, BZU, BZL;      // best iterate
     int FACP, FACL, PV, YB;              // per knot: P_t (NX x NX), [Lxu ; Luu] (NT x NU, 1 / L_jj on the diagonal), p_t (NX), Luu^-1 h_u (NU)
@@ -64,7 +65,7 @@ __host__ __device__ inline Lay layout(int nx, int nu, int T)
     int o = 0;
     auto take = [&](int n) { const int at = o; o += n; return at; };
     L.X = take(T * nt); L.Y = take(T * nx); L.SU = take(T * nu); L.SL = take(T * nu); L.ZU = take(T * nu); L.ZL = take(T * nu);
-    L.RX = take(T * nt); L.RY = take(T * nx); L.RZU = take(T * nu); L.RZL = take(T * nu);
+    L.RY = take(T * nx); L.RZU = take(T * nu); L.RZL = take(T * nu);
     L.DX = take(T * nt); L.DY = take(T * nx); L.DSU = take(T * nu); L.DSL = take(T * nu); L.DZU = take(T * nu); L.DZL = take(T * nu);
     L.BX = take(T * nt); L.BY = take(T * nx); L.BSU = take(T * nu); L.BSL = take(T * nu); L.BZU = take(T * nu); L.BZL = take(T * nu);
     o = (o + 1) & ~1; L.FACP = take(T * nx * nx); o = (o + 1) & ~1; L.FACL = take(T * nt * nu);     // 16-byte aligned: DMA sources
@@ -559,7 +560,7 @@ __device__ __forceinline__ bool factor_fused(const Ctx<C> &K0, double &nx2, doub
                 ny2 = fma(ry, ry, ny2);
             }
         }
-        if (r < NT) { w[L.RX + t * NT + r] = rx; nx2 = fma(rx, rx, nx2); }
+        if (r < NT) nx2 = fma(rx, rx, nx2);           // rx itself is only needed here (q below): not stored
         q += rx;
         // ---- affine right-hand side: h = q + F'(P_{t+1} e + p_{t+1})
         double h = q;
@@ -620,15 +621,8 @@ __device__ __forceinline__ void rhs_load(const Ctx<C> &K, int t, double (&v)[R_N
     if (MODE == INIT) {            // batch.py:60-74: rx = p, rs = 0, rz = -h, ry = -b with d = 1
         if (NEED_Q && r < NT) v[R_A] = K.cvec(t);
         if (NEED_E && K.xl && t < T - 1) v[R_H] = K.fvec(t);
-    } else if (MODE == AFFINE) {   // rx, rs = z, rz, ry of the iterate
-        if (NEED_Q) {
-            if (r < NT) v[R_A] = w[L.RX + t * NT + r];
-            if (K.ul) {
-                const int iu = t * NU + K.a;
-                v[R_B] = w[L.SU + iu]; v[R_C] = w[L.SL + iu]; v[R_D] = w[L.ZU + iu]; v[R_E] = w[L.ZL + iu];
-                v[R_F] = w[L.RZU + iu]; v[R_G] = w[L.RZL + iu];
-            }
-        }
+    } else if (MODE == AFFINE) {   // rx, rs = z, rz, ry of the iterate: q_t is formed and used inside factor_fused
+        static_assert(!(MODE == AFFINE && NEED_Q), "the affine backward sweep is part of factor_fused");
         if (NEED_E && K.xl && t < T - 1) v[R_H] = w[L.RY + t * NX + r];
     } else if (MODE == CORRECTOR) {   // rx = 0, rs = (-mu sig + ds_aff dz_aff) / s, rz = ry = 0
         if (NEED_Q && K.ul) {
@@ -645,7 +639,6 @@ template <class C, int MODE>
 __device__ __forceinline__ double rhs_q(const Ctx<C> &K, const double (&v)[R_N], double musig)
 {
     if (MODE == INIT) return v[R_A] - (K.ul ? K.uu + K.ulo : 0.0);
-    if (MODE == AFFINE) return K.ul ? v[R_A] - ((v[R_D] - v[R_D] * frcp(v[R_B]) * v[R_F]) - (v[R_E] - v[R_E] * frcp(v[R_C]) * v[R_G])) : v[R_A];
     if (MODE == CORRECTOR) return K.ul ? -((-musig + v[R_D] * v[R_E]) * frcp(v[R_B]) - (-musig + v[R_F] * v[R_G]) * frcp(v[R_C])) : 0.0;
     return v[R_A];
 }
