@@ -96,3 +96,39 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("offline oracle", ""), os.path.join(dp, f)
+
+
+def test_header_constants_match_the_binding(lib):
+    """Every DQP_FLAG_* / DQP_DYN_* value of include/dqp.h is the one the ctypes binding uses, the flags are
+    distinct bits, and the library reports the header's version."""
+    from diff_qp_mpc_amd import _lib
+    src = open(os.path.join(ROOT, "include", "dqp.h")).read()
+    flags = {k: int(v) for k, v in re.findall(r"#define\s+(DQP_FLAG_[A-Z_]+)\s+(\d+)u", src)}
+    assert len(flags) >= 7
+    for k, v in flags.items():
+        assert getattr(_lib, k) == v, k
+        assert v & (v - 1) == 0, k
+    assert len(set(flags.values())) == len(flags)
+    dyn = {k: int(v) for k, v in re.findall(r"(DQP_DYN_[A-Z0-9_]+)\s*=\s*(\d+)", src)}
+    assert dyn.get("DQP_DYN_REXQUADROTOR") == 6
+    version = int(re.search(r"#define\s+DQP_VERSION\s+(\d+)", src).group(1))
+    assert lib.dqp_version() == version
+
+
+def test_stagewise_workspace_bytes_is_a_host_function(lib):
+    """dqp_mpc_qp_workspace_bytes for the stage-wise kernels: per problem the iterate, residual, direction
+    and best-iterate vectors, the factor rows as P_t (n x n) and [Lxu ; Luu] (nt x m), p_t and Luu^-1 h_u;
+    four problems per wavefront, so the batch is rounded up to a multiple of four."""
+    from diff_qp_mpc_amd import _lib
+    for n, m, T, B in [(12, 4, 30, 8192), (12, 4, 30, 5), (6, 1, 40, 9), (3, 1, 30, 1024)]:        # nz > 64: no dense kernel
+        nt = n + m
+        it = T * (nt + n + 4 * m)
+        per = it + T * (n + 2 * m) + it + it          # X..ZL | RY RZU RZL | DX..DZL | BX..BZL
+        per += per & 1
+        per += T * n * n
+        per += per & 1
+        per += T * nt * m + T * n + T * m
+        per += per & 1
+        d = _lib.dqp_mpc_dims(B, n, m, T, 1, 0)
+        assert lib.dqp_mpc_qp_supported(ctypes.byref(d)) == 1
+        assert lib.dqp_mpc_qp_workspace_bytes(ctypes.byref(d)) == (B + 3) // 4 * 4 * per * 8, (n, m, T, B)
