@@ -901,6 +901,8 @@ static int mpc_params(const dqp_mpc_dims *md, const dqp_opts *opts, KParams &P, 
         if (rc != DQP_OK) return rc;
         kind = MPC_R16N;
     } else if (ric_supported(md->n_state, md->n_ctrl)) {
+        // the stage-wise kernels address a wavefront's four workspaces with 32-bit byte offsets
+        if (md->T > 200000 || ric_workspace_doubles(md->n_state, md->n_ctrl, md->T) * 8 * 4 > 0x7fffffffLL) return DQP_ERR_TOO_LARGE;
         P.stamps = nullptr;
         P.B = d.nbatch; P.N = d.nz; P.M = d.nineq; P.E = d.neq;
         fill_opts(opts, P);

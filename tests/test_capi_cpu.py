@@ -132,3 +132,14 @@ def test_stagewise_workspace_bytes_is_a_host_function(lib):
         d = _lib.dqp_mpc_dims(B, n, m, T, 1, 0)
         assert lib.dqp_mpc_qp_supported(ctypes.byref(d)) == 1
         assert lib.dqp_mpc_qp_workspace_bytes(ctypes.byref(d)) == (B + 3) // 4 * 4 * per * 8, (n, m, T, B)
+
+
+def test_stagewise_horizon_limit(lib):
+    """The stage-wise kernels address a wavefront's workspaces with 32-bit byte offsets: a horizon whose four
+    workspaces exceed 2 GB is refused on the host (DQP_ERR_TOO_LARGE = -2), not launched."""
+    from diff_qp_mpc_amd import _lib
+    d = _lib.dqp_mpc_dims(8, 12, 4, 190000, 1, 0)
+    assert lib.dqp_mpc_qp_supported(ctypes.byref(d)) == 0
+    assert lib.dqp_mpc_qp_workspace_bytes(ctypes.byref(d)) == 0
+    d = _lib.dqp_mpc_dims(8, 12, 4, 2000, 1, 0)
+    assert lib.dqp_mpc_qp_supported(ctypes.byref(d)) == 1

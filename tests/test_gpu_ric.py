@@ -362,3 +362,37 @@ def test_stagewise_lds_resident_equals_global_workspace(n, m, T, B):
     Q, p, G, h, A, b = assemble(*data)
     o = oracle.dense_forward(Q, p, G, h, A, b)
     np.testing.assert_allclose(tau_l.reshape(B, -1), o["zhat"], **ZT)
+
+
+@pytest.mark.parametrize("n,m,T,B", [(12, 4, 30, 37), (4, 2, 6, 9)])
+def test_stagewise_inputs_and_workspace_only_8_byte_aligned(n, m, T, B):
+    """The knot prefetch moves 16-byte pieces by LDS-DMA; a caller's C, c, F, f and workspace are doubles and
+    promise 8-byte alignment only (a view into a larger tensor): same result bit for bit."""
+    from diff_qp_mpc_amd import _lib
+    lib = _lib.load()
+    C0, c0, F0, f0, x0, lo, hi = [dev(a) for a in problem(n, m, T, B, seed=3 * n + T)]
+    nt = n + m
+    kw = dict(dtype=torch.float64, device="cuda")
+    dims = _lib.dqp_mpc_dims(B, n, m, T, 1, 0)
+    wsb = int(lib.dqp_mpc_qp_workspace_bytes(ctypes.byref(dims)))
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    outs = []
+    for shift in (0, 1):
+        def placed(t):
+            buf = torch.empty(t.numel() + 2, **kw)
+            v = buf[shift:shift + t.numel()]
+            v.copy_(t.reshape(-1))
+            return v
+        C, c, F, f = placed(C0), placed(c0), placed(F0), placed(f0)
+        ws = torch.empty(wsb // 8 + 2, **kw)[shift:]
+        assert C.data_ptr() % 16 == 8 * shift and ws.data_ptr() % 16 == 8 * shift
+        tau = torch.empty(B, T, nt, **kw); lam = torch.empty(B, 2 * T * m, **kw); slack = torch.empty(B, 2 * T * m, **kw)
+        nu = torch.empty(B, T * n, **kw); info = torch.empty(B, 2, dtype=torch.int32, device="cuda"); resid = torch.empty(B, **kw)
+        opts = _lib.dqp_opts(1e-12, 1e-10, 20, 3, _lib.DQP_FLAG_RIC_GLOBAL_WS, 0)
+        rc = lib.dqp_mpc_qp_forward(ctypes.byref(dims), ctypes.byref(opts), P(C), P(c), P(F), P(f), P(x0), P(lo), P(hi),
+                                    P(tau), P(lam), P(nu), P(slack), P(info), P(resid), P(ws), None, None)
+        torch.cuda.synchronize()
+        assert rc == 0
+        assert float(resid.max()) < 1e-9
+        outs.append(tau.cpu().numpy())
+    np.testing.assert_array_equal(outs[0], outs[1])
