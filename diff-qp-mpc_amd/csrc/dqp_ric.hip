@@ -876,8 +876,9 @@ __device__ __forceinline__ void ew_axpy(double *__restrict__ y, const double *__
         if (i + 16 * k < n) y[i + 16 * k] = fma(alpha, xv[k], yv[k]);
 }
 
-// the iterate (X, Y, SU, SL, ZU, ZL: contiguous at the head of the layout) -> the best-iterate arrays,
-// and, under the batch rule, -> this iteration's snapshot (the finish pass picks the right one)
+// the iterate (X, Y, SU, SL, ZU, ZL: contiguous at the head of the layout) -> the best-iterate arrays, or,
+// under the batch rule, -> this iteration's snapshot only: the snapshots are then the best-iterate store
+// (the outputs are read back from the best one, the finish pass picks an earlier one where the rule says so)
 template <class C>
 __device__ __forceinline__ void copy_best(const Ctx<C> &K, double *snap)
 {
@@ -886,7 +887,11 @@ __device__ __forceinline__ void copy_best(const Ctx<C> &K, double *snap)
     const Lay &L = K.L;
     const int T = K.T, r = K.r;
     const int len = T * (NT + NX + 4 * NU);
-    ew_copy(w + L.BX, (snap && K.live) ? snap : nullptr, w + L.X, len, r);      // BX, BY, BSU, BSL, BZU, BZL mirror X .. ZL
+    if (snap) {
+        if (K.live) ew_copy(snap, nullptr, w + L.X, len, r);
+    } else {
+        ew_copy(w + L.BX, nullptr, w + L.X, len, r);      // BX, BY, BSU, BSL, BZU, BZL mirror X .. ZL
+    }
 }
 
 #ifndef DQP_RIC_WPE
@@ -960,7 +965,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
 
     double best = INFINITY;
     bool have_best = false, done = false;
-    int nNot = 0, iters = 0;
+    int nNot = 0, iters = 0, best_it = 0;
     for (int it = 0; it < maxIter; ++it) {
         double nx2, nz2, ny2, sz;
         const bool pd = factor_fused<C, DYN>(K, nx2, nz2, ny2, sz);      // residuals + factorisation + affine rhs
@@ -970,7 +975,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
         if (!done) {
             iters = it + 1;
             if (!have_best || resid < best) {
-                nNot = 0; have_best = true; best = resid;
+                nNot = 0; have_best = true; best = resid; best_it = it;
                 copy_best<C>(K, P.snap ? P.snap + ((long long)it * P.B + qp) * (long long)(T * (NT + NX + 4 * NU)) : nullptr);
             }
             else nNot += 1;
@@ -1010,11 +1015,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
     // ---- outputs in the reference's orderings
     if (live) {
         const int nz = T * NT, neq = T * NX, hm = T * NU;
-        for (int i = r; i < nz; i += 16) P.zhat[qp * nz + i] = w[L.BX + i];
-        for (int i = r; i < neq; i += 16) P.nu[qp * neq + i] = w[L.BY + i];
+        const double *bx = (P.snap && have_best) ? P.snap + ((long long)best_it * P.B + qp) * (long long)(nz + neq + 4 * hm) : w + L.BX;
+        const double *by = bx + nz, *bs = by + neq, *bz = bs + 2 * hm;         // [X | Y | SU SL | ZU ZL]
+        for (int i = r; i < nz; i += 16) P.zhat[qp * nz + i] = bx[i];
+        for (int i = r; i < neq; i += 16) P.nu[qp * neq + i] = by[i];
         for (int i = r; i < hm; i += 16) {
-            P.lam[qp * 2 * hm + i] = w[L.BZU + i];       P.lam[qp * 2 * hm + hm + i] = w[L.BZL + i];
-            P.slack[qp * 2 * hm + i] = w[L.BSU + i];     P.slack[qp * 2 * hm + hm + i] = w[L.BSL + i];
+            P.lam[qp * 2 * hm + i] = bz[i];       P.lam[qp * 2 * hm + hm + i] = bz[hm + i];
+            P.slack[qp * 2 * hm + i] = bs[i];     P.slack[qp * 2 * hm + hm + i] = bs[hm + i];
         }
         if (r == 0) {
             if (P.info) { P.info[2 * qp] = status; P.info[2 * qp + 1] = iters; }
