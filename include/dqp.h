@@ -128,7 +128,7 @@ const char *dqp_error_string(int code);
 size_t dqp_workspace_bytes(const dqp_dims *dims);
 
 /* Bytes of the device buffer DQP_FLAG_BATCH_TERMINATION needs (per-iteration residual history,
- * the batch reduction's accumulators, the redo list and -- sizes served by the null-space kernels --
+ * the batch reduction's accumulators, each problem's best-iteration index and -- sizes served by the null-space kernels --
  * max_iter iterate snapshots of (nz - neq) + 2 nineq + 2 doubles per problem: 12 KB per QP at the
  * metric size); 0 without the flag.  max_iter <= 64. */
 size_t dqp_termination_bytes(const dqp_dims *dims, const dqp_opts *opts);
@@ -253,7 +253,7 @@ int dqp_mpc_assemble_backward(const dqp_mpc_dims *dims, const double *dQ, const 
  */
 int dqp_mpc_qp_supported(const dqp_mpc_dims *dims);
 size_t dqp_mpc_qp_workspace_bytes(const dqp_mpc_dims *dims);
-/* the `termination` buffer of dqp_mpc_qp_forward under DQP_FLAG_BATCH_TERMINATION (history, redo list and the
+/* the `termination` buffer of dqp_mpc_qp_forward under DQP_FLAG_BATCH_TERMINATION (history, best-iteration list and the
  * improving iterates of pass 1, from which pass 2 finishes without solving again); 0 without the flag */
 size_t dqp_mpc_qp_termination_bytes(const dqp_mpc_dims *dims, const dqp_opts *opts);
 int dqp_mpc_qp_forward(const dqp_mpc_dims *dims, const dqp_opts *opts, const double *C, const double *c,
