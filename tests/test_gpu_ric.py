@@ -342,7 +342,11 @@ def test_stagewise_more_size_pairs(n, m, T, B):
     np.testing.assert_allclose(grads[1], dc, err_msg="dc", **GT)
 
 
-@pytest.mark.parametrize("n,m,T,B", [(3, 1, 10, 9), (4, 2, 6, 130), (6, 1, 5, 7), (12, 4, 4, 6), (3, 3, 8, 5)])
+ALL_PAIRS = [(12, 4), (3, 3), (3, 1), (4, 1), (6, 1), (2, 1), (4, 2), (5, 1), (8, 1), (2, 2), (3, 2), (6, 2), (8, 2), (6, 3),
+             (4, 4), (8, 4), (10, 4), (12, 2)]        # DQP_RIC_SIZES of csrc/dqp_ric.hip
+
+
+@pytest.mark.parametrize("n,m,T,B", [(3, 1, 10, 9), (4, 2, 6, 130), (12, 4, 4, 6)] + [(n, m, 5, 6) for n, m in ALL_PAIRS])
 def test_stagewise_lds_resident_equals_global_workspace(n, m, T, B):
     """Short horizons keep the whole problem (C, F, c, f, iterates, factors) in LDS; DQP_FLAG_RIC_GLOBAL_WS pins the
     same sizes to the caller's workspace (the path long horizons take, LDS-DMA prefetch of every knot).  Same
