@@ -420,40 +420,48 @@ __device__ __forceinline__ bool factor(const Ctx<C> &K0, bool unit, bool clampd)
     return ok;
 }
 
-// f(x_t, u_t)[r] of a registered model for the knot distributed as `tau`: every lane gathers the knot,
-// evaluates the step (redundantly: the models are a few hundred FLOP) and keeps its own component.
+// The true-dynamics residual of every knot (the reference's dyn_res closure, qp_wrapper.py:309,316 ->
+// batch_LU.py:97), ry_t = f(x_t, u_t) - x_{t+1}, before the fused sweep: lane r of a problem's row evaluates
+// the registered model at knot base + r, sixteen knots of the problem at a time.  (The first version evaluated
+// the model inside the fused sweep, every lane of the row the same knot: sixteen times the work, and the
+// registers of an RK4 step of the quadrotor spilled around the Riccati update.)
+template <class C, class Map> constexpr bool model_fits() { return Map::NX == C::NX && Map::NU == C::NU; }
 template <class C, class Map>
-__device__ __forceinline__ double model_component(double tau, double dt, int r)
+__device__ __forceinline__ void model_residuals_of(const Ctx<C> &K)
 {
-    if constexpr (Map::NX == C::NX && Map::NU == C::NU) {
-        double z[C::NT], xn[C::NX];
+    if constexpr (model_fits<C, Map>()) {
+        constexpr int NX = C::NX, NT = C::NT;
+        double *w = K.w;
+        const Lay &L = K.L;
+        for (int base = 0; base < K.T - 1; base += 16) {
+            const int t = base + K.r;
+            if (t < K.T - 1) {
+                double z[NT], xn[NX];
 #pragma unroll
-        for (int j = 0; j < C::NT; ++j) z[j] = rb(tau, j);
-        Map::template step<double>(z, z + C::NX, dt, xn);
-        double v = 0.0;
+                for (int j = 0; j < NT; ++j) z[j] = w[L.X + t * NT + j];
+                Map::template step<double>(z, z + NX, K.P.dynDt, xn);
 #pragma unroll
-        for (int j = 0; j < C::NX; ++j) v = (r == j) ? xn[j] : v;
-        return v;
-    } else {
-        return 0.0;
+                for (int j = 0; j < NX; ++j) w[L.RY + t * NX + j] = xn[j] - w[L.X + (t + 1) * NT + j];
+            }
+        }
     }
 }
 template <class C>
-__device__ __forceinline__ double model_next(int dyn_id, double tau, double dt, int r)
+__device__ __forceinline__ void model_residuals(const Ctx<C> &K0)
 {
     using namespace dqp::dyn;
-    switch (dyn_id) {
-    case DQP_DYN_PENDULUM1L: return model_component<C, Robot<Pendulum1l>>(tau, dt, r);
-    case DQP_DYN_CARTPOLE1L: return model_component<C, Robot<Cartpole1l>>(tau, dt, r);
-    case DQP_DYN_CARTPOLE2L: return model_component<C, Robot<Cartpole2l>>(tau, dt, r);
-    case DQP_DYN_PENDULUM_EULER: return model_component<C, PendulumEuler>(tau, dt, r);
-    case DQP_DYN_PENDULUM_DX: return model_component<C, PendulumDx>(tau, dt, r);
-    case DQP_DYN_REXQUADROTOR: return model_component<C, RexQuadrotor>(tau, dt, r);
-    default: return 0.0;
+    const Ctx<C> K = fresh<C>(K0);
+    switch (K.P.dynId) {
+    case DQP_DYN_PENDULUM1L: model_residuals_of<C, Robot<Pendulum1l>>(K); break;
+    case DQP_DYN_CARTPOLE1L: model_residuals_of<C, Robot<Cartpole1l>>(K); break;
+    case DQP_DYN_CARTPOLE2L: model_residuals_of<C, Robot<Cartpole2l>>(K); break;
+    case DQP_DYN_PENDULUM_EULER: model_residuals_of<C, PendulumEuler>(K); break;
+    case DQP_DYN_PENDULUM_DX: model_residuals_of<C, PendulumDx>(K); break;
+    case DQP_DYN_REXQUADROTOR: model_residuals_of<C, RexQuadrotor>(K); break;
+    default: break;
     }
 }
 
-template <class C, class Map> constexpr bool model_fits() { return Map::NX == C::NX && Map::NU == C::NU; }
 template <class C> constexpr bool has_model()
 {
     using namespace dqp::dyn;
@@ -494,7 +502,7 @@ __device__ __forceinline__ bool factor_fused(const Ctx<C> &K0, double &nx2, doub
         }
         if (K.xl) {
             v[V_YP] = w[L.Y + (t >= 1 ? t - 1 : T - 1) * NX + r];
-            if (!DYN && t < T - 1) v[V_MF] = K.fvec(t);
+            if (t < T - 1) v[V_MF] = DYN ? w[L.RY + t * NX + r] : K.fvec(t);      // DYN: ry_t itself (model_residuals)
             if (t == 0) v[V_X0] = K.P.mx0[K.qp * NX + r];
         }
     };
@@ -539,14 +547,15 @@ __device__ __forceinline__ bool factor_fused(const Ctx<C> &K0, double &nx2, doub
 #pragma unroll
             for (int i = 0; i < NX; ++i) acc = fma(fcol[i], rb(y_t, i), acc);
             rx += acc;
-            // ry_t: the linearised dynamics, or the registered model itself (the reference's dyn_res closure,
-            // qp_wrapper.py:309,316 -> batch_LU.py:97)
-            double fx;
-            if constexpr (DYN) fx = model_next<C>(K.P.dynId, tau, K.P.dynDt, r);
-            else fx = mv_row<NT>(frow, tau) + cur[V_MF];
+            // ry_t: the linearised dynamics, or the registered model's own residual (computed by model_residuals)
+            double fx = 0.0;
+            if constexpr (!DYN) fx = mv_row<NT>(frow, tau) + cur[V_MF];       // (row broadcasts: every lane takes part)
             if (K.xl) {
-                e = fx - x_next;
-                w[L.RY + t * NX + r] = e;
+                if constexpr (DYN) e = cur[V_MF];
+                else {
+                    e = fx - x_next;
+                    w[L.RY + t * NX + r] = e;
+                }
                 ny2 = fma(e, e, ny2);
             }
             add_FtPF<C>(H, Pn, frow, fcol);
@@ -968,6 +977,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
     int nNot = 0, iters = 0, best_it = 0;
     for (int it = 0; it < maxIter; ++it) {
         double nx2, nz2, ny2, sz;
+        if constexpr (DYN) model_residuals<C>(K);
         const bool pd = factor_fused<C, DYN>(K, nx2, nz2, ny2, sz);      // residuals + factorisation + affine rhs
         nx2 = row_sum(nx2); nz2 = row_sum(nz2); ny2 = row_sum(ny2); sz = row_sum(sz);
         const double mu = fabs(sz / nineq);
