@@ -198,11 +198,87 @@ template <int N, int M_> struct LinStepT { static constexpr bool LIN = true, FIX
 template <class Map> struct ModelStep { static constexpr bool LIN = false, FIXED = true; static constexpr int NX = Map::NX, NU = Map::NU; using M = Map; };
 #define DQP_LIN_SIZES X(3, 3) X(3, 1) X(4, 1) X(6, 1) X(2, 1) X(4, 2) X(3, 2) X(12, 4)
 
+// 0.5 tau' C tau + c' tau with the knot's C_t, c_t in registers (same summation order as stage_cost)
+template <int NX, int NU>
+__device__ __forceinline__ double stage_cost_regs(const double (&Ct)[(NX + NU) * (NX + NU)], const double (&ct)[NX + NU],
+                                                  const double (&xs)[NX], const double (&us)[NU])
+{
+    constexpr int NT = NX + NU;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const double ti = i < NX ? xs[i < NX ? i : 0] : us[i >= NX ? i - NX : 0];
+        double row = 0.0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) row += Ct[i * NT + j] * (j < NX ? xs[j < NX ? j : 0] : us[j >= NX ? j - NX : 0]);
+        acc += ti * (0.5 * row + ct[i]);
+    }
+    return acc;
+}
+
+// Registered models with small knots: the thread is a chain of T knots "load C_t, c_t, u_t, du_t -> cost ->
+// model step", one memory round trip per knot and a second pass for the cost of the current trajectory.  Here
+// the next knot's inputs are loaded right after the cost of this one, under its model step (atan2 / sincos /
+// an RK4 step: long enough to cover the latency), and round 0 evaluates both costs from the one copy of C_t.
+template <class S>
+__device__ __forceinline__ void line_search_model(const LsP &P, long long b)
+{
+    constexpr int NX = S::NX, NU = S::NU, NT = NX + NU;
+    const double *__restrict__ pC = P.C, *__restrict__ pc = P.c, *__restrict__ pu = P.u, *__restrict__ pdu = P.du;
+    const double *__restrict__ px = P.x, *__restrict__ px0 = P.x0;
+    double *__restrict__ pxn = P.xn, *__restrict__ pun = P.un;
+    const int T = P.T;
+    const long long B = P.B;
+    double Ct[NT * NT], ct[NT], u0[NU], du[NU], xc[NX];
+    auto load = [&](int t, bool current) {
+        const long long k = (long long)t * B + b;
+#pragma unroll
+        for (int i = 0; i < NT * NT; ++i) Ct[i] = pC[k * (NT * NT) + i];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) ct[i] = pc[k * NT + i];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) { u0[i] = pu[k * NU + i]; du[i] = pdu ? pdu[k * NU + i] : 0.0; }
+        if (current) {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xc[i] = px[k * NX + i];
+        }
+    };
+    double alpha = 1.0, cost_try = 0.0, cost_here = 0.0;
+    for (int round = 0; round < P.max_iter; ++round) {
+        double xs[NX], us[NU], nx[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xs[i] = px0[b * NX + i];
+        cost_try = 0.0;
+        load(0, round == 0);
+        for (int t = 0; t < T; ++t) {
+            const long long k = (long long)t * B + b;
+#pragma unroll
+            for (int i = 0; i < NU; ++i) { us[i] = pdu ? u0[i] + du[i] * alpha : u0[i]; pun[k * NU + i] = us[i]; }
+#pragma unroll
+            for (int i = 0; i < NX; ++i) pxn[k * NX + i] = xs[i];
+            if (round == 0) cost_here += stage_cost_regs<NX, NU>(Ct, ct, xc, u0);
+            cost_try += stage_cost_regs<NX, NU>(Ct, ct, xs, us);
+            if (t == T - 1) break;
+            load(t + 1, round == 0);
+            ls_step<typename S::M>(xs, us, P.dt, nx);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) xs[i] = nx[i];
+        }
+        if (cost_try < cost_here) break;            // improved: this alpha stands
+        alpha *= P.decay;                           // qp_wrapper.py:431-432
+    }
+    P.alpha[b] = alpha;
+    P.cost[b] = cost_try;
+}
+
 template <class S>
 __global__ __launch_bounds__(64) void line_search_kernel(LsP P)
 {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= P.B) return;
+    if constexpr (!S::LIN && (S::NX + S::NU) * (S::NX + S::NU) <= 64) {
+        if (P.C) { line_search_model<S>(P, b); return; }
+    }
     const int n = S::FIXED ? S::NX : P.n, m = S::FIXED ? S::NU : P.m, T = P.T, nt = n + m;
     double cost_here = 0.0;
     for (int t = 0; t < T && P.C; ++t) {
