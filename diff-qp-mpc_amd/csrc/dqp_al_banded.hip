@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dqp.h"
 #include "dqp_r16_prims.h"
@@ -61,25 +62,95 @@ template <class Map> struct BandCfg {
     static_assert(NT <= 16, "one knot must fit a 16-lane DPP row");
 };
 
+// ---- lane groups.  A knot of nt <= 8 rows uses half of a 16-lane DPP row; the models this solver is run on
+// in the reference's experiments (pendulum nt 3, cartpole-1 nt 5, cartpole-2 nt 7) are all of that kind, and two
+// thirds of the kernel is the per-lane forward-mode model evaluation, which does not care how wide a group is.
+// Grp<8> puts one problem on each HALF row (8 per wavefront): a broadcast is two bank-masked row_newbcast moves
+// (lanes 0-7 take lane k, lanes 8-15 take lane 8 + k) instead of one, a group sum three DPP steps instead of four.
+template <int G> struct Grp;
+template <> struct Grp<16> {
+    __device__ __forceinline__ static double rb(double v, int k) { return dqp::r16::rb(v, k); }
+    __device__ __forceinline__ static double sum(double v) { return row_sum(v); }
+};
+template <int K> __device__ __forceinline__ double rb8k(double v)
+{
+    const double lo = __builtin_amdgcn_update_dpp(v, v, 0x150 + K, 0xf, 0x3, false);       // banks 0,1: lanes 0-7 of the row
+    return __builtin_amdgcn_update_dpp(lo, v, 0x158 + K, 0xf, 0xc, false);                  // banks 2,3: lanes 8-15
+}
+template <> struct Grp<8> {
+    __device__ __forceinline__ static double rb(double v, int k)
+    {
+        switch (k & 7) {
+        case 0: return rb8k<0>(v);  case 1: return rb8k<1>(v);  case 2: return rb8k<2>(v);  case 3: return rb8k<3>(v);
+        case 4: return rb8k<4>(v);  case 5: return rb8k<5>(v);  case 6: return rb8k<6>(v);  default: return rb8k<7>(v);
+        }
+    }
+    __device__ __forceinline__ static double sum(double v)
+    {
+        v += dppd<0x141>(v);        // row_half_mirror: l <-> 7 - l
+        v += dppd<0xb1>(v);         // quad_perm [1,0,3,2]
+        v += dppd<0x4e>(v);         // quad_perm [2,3,0,1]
+        return v;
+    }
+};
+
+// Cholesky / triangular solves of one row-distributed N x N block per group (dqp_r16_prims.h's chol_rows /
+// trsv_rows at S = 1, on the group's broadcast)
+template <int G, int N>
+__device__ __forceinline__ bool chol_g(double (&L)[1][N], double (&rd)[1], int r)
+{
+    if constexpr (G == 16) return chol_rows<1, N>(L, rd, r);
+    else {
+        bool ok = true;
+        rd[0] = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            double dk = Grp<G>::rb(L[0][k], k);
+            if (!(dk > 0.0)) { ok = false; dk = 1.0; }
+            const double ri = frsqrt(dk);
+            if (r == k) rd[0] = ri;
+            PIN(rd[0]);
+            const double col = (r >= k) ? L[0][k] * ri : 0.0;
+            L[0][k] = col;
+#pragma unroll
+            for (int j = k + 1; j < N; ++j) L[0][j] = fma(-col, Grp<G>::rb(col, j), L[0][j]);
+        }
+        return ok;
+    }
+}
+template <int G, int N>
+__device__ __forceinline__ void trsv_g(const double (&L)[1][N], const double (&rd)[1], double (&b)[1], int r)
+{
+    if constexpr (G == 16) trsv_rows<1, N>(L, rd, b, r);
+    else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double yk = Grp<G>::rb(b[0] * rd[0], k);
+            b[0] = (r == k) ? yk : fma(r > k ? -L[0][k] : 0.0, yk, b[0]);
+        }
+    }
+}
 // b <- L^-T b for a row-distributed lower-triangular NT x NT matrix in registers
-template <int NT>
+template <int G, int NT>
 __device__ __forceinline__ void trsvT_rows(const double (&L)[1][NT], const double (&rd)[1], double (&b)[1], int r)
 {
 #pragma unroll
     for (int j = NT - 1; j >= 0; --j) {
         const double part = (r > j && r < NT) ? L[0][j] * b[0] : 0.0;
-        const double tot = row_sum(part);
+        const double tot = Grp<G>::sum(part);
         if (r == j) b[0] = (b[0] - tot) * rd[0];
     }
 }
 
-template <class Map>
+template <class Map, int G>
 __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
 {
     using C = BandCfg<Map>;
+    using Gr = Grp<G>;
     constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
-    const int lane = threadIdx.x, r = lane & 15;
-    long long b = (long long)blockIdx.x * 4 + (lane >> 4);
+    static_assert(NT <= G, "a knot must fit its lane group");
+    const int lane = threadIdx.x, r = lane & (G - 1);
+    long long b = (long long)blockIdx.x * (64 / G) + lane / G;
     const bool live = b < P.B;
     if (!live) b = P.B - 1;
     const int T = P.T, neq = T * NX;
@@ -161,7 +232,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
         for (int c = 0; c < NT; ++c) {
             double a = 0.0;
 #pragma unroll
-            for (int j = 0; j < NX; ++j) a = fma(Jc[j], rb(Jc[j], c), a);
+            for (int j = 0; j < NX; ++j) a = fma(Jc[j], Gr::rb(Jc[j], c), a);
             H[0][c] = rho * a + ((r == c) ? dg : 0.0);
         }
         if (t > 0) {
@@ -169,7 +240,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             for (int i = 0; i < NX; ++i) {
 #pragma unroll
                 for (int j = 0; j <= i; ++j) {
-                    const double tot = row_sum(Mprev[i] * Mprev[j]);
+                    const double tot = Gr::sum(Mprev[i] * Mprev[j]);
                     if (r == i) H[0][j] -= tot;
                     if (r == j && i != j) H[0][i] -= tot;
                 }
@@ -177,23 +248,23 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
         }
 #pragma unroll
         for (int c = 0; c < NT; ++c) H[0][c] = inT ? H[0][c] : ((r == c) ? 1.0 : 0.0);
-        if (!chol_rows<1, NT>(H, rd, r) && bad == 0) bad = t + 1;
+        if (!chol_g<G, NT>(H, rd, r) && bad == 0) bad = t + 1;
         // ---- right-hand side: y_t = L_tt^-1 (-g_t - L_{t,t-1} y_{t-1})
         double y[1] = {inT ? -g : 0.0};
         if (t > 0) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                const double tot = row_sum(Mprev[i] * yprev[0]);
+                const double tot = Gr::sum(Mprev[i] * yprev[0]);
                 if (r == i) y[0] -= tot;
             }
         }
-        trsv_rows<1, NT>(H, rd, y, r);
+        trsv_g<G, NT>(H, rd, y, r);
         // ---- M_t = L_tt^-1 H_{t+1,t}^T: column j of it is the distributed vector -rho J[j][:]
         double M[NX];
 #pragma unroll
         for (int j = 0; j < NX; ++j) {
             double v[1] = {-rho * Jc[j]};
-            trsv_rows<1, NT>(H, rd, v, r);
+            trsv_g<G, NT>(H, rd, v, r);
             M[j] = inT ? v[0] : 0.0;
         }
         // ---- keep the knot's factor rows (banded form) and y_t
@@ -223,9 +294,9 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
         double v[1] = {inT ? P.upd[b * (long long)T * NT + t * NT + (inT ? r : 0)] : 0.0};
         if (t < T - 1) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) v[0] = fma(-M[j], rb(xnext[0], j), v[0]);
+            for (int j = 0; j < NX; ++j) v[0] = fma(-M[j], Gr::rb(xnext[0], j), v[0]);
         }
-        trsvT_rows<NT>(L, rd, v, r);
+        trsvT_rows<G, NT>(L, rd, v, r);
         if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = v[0];
         xnext[0] = inT ? v[0] : 0.0;
     }
@@ -234,13 +305,15 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
 
 // out = -(L L^T)^-1 rhs with the banded factor a forward launch left in `fac`
 // (NewtonAL.backward, al_utils.py:477-480)
-template <class Map>
+template <class Map, int G>
 __global__ __launch_bounds__(64) void al_banded_solve_kernel(BandP P)
 {
     using C = BandCfg<Map>;
+    using Gr = Grp<G>;
     constexpr int NX = C::NX, NT = C::NT;
-    const int lane = threadIdx.x, r = lane & 15;
-    long long b = (long long)blockIdx.x * 4 + (lane >> 4);
+    static_assert(NT <= G, "a knot must fit its lane group");
+    const int lane = threadIdx.x, r = lane & (G - 1);
+    long long b = (long long)blockIdx.x * (64 / G) + lane / G;
     const bool live = b < P.B;
     if (!live) b = P.B - 1;
     const int T = P.T;
@@ -261,11 +334,11 @@ __global__ __launch_bounds__(64) void al_banded_solve_kernel(BandP P)
         if (t > 0) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
-                const double tot = row_sum(Mprev[i] * yprev);
+                const double tot = Gr::sum(Mprev[i] * yprev);
                 if (r == i) y[0] -= tot;
             }
         }
-        trsv_rows<1, NT>(L, rd, y, r);
+        trsv_g<G, NT>(L, rd, y, r);
         if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = y[0];
 #pragma unroll
         for (int j = 0; j < NX; ++j) Mprev[j] = M[j];
@@ -283,22 +356,46 @@ __global__ __launch_bounds__(64) void al_banded_solve_kernel(BandP P)
         double v[1] = {inT ? P.upd[b * (long long)T * NT + t * NT + (inT ? r : 0)] : 0.0};
         if (t < T - 1) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) v[0] = fma(-M[j], rb(xnext[0], j), v[0]);
+            for (int j = 0; j < NX; ++j) v[0] = fma(-M[j], Gr::rb(xnext[0], j), v[0]);
         }
-        trsvT_rows<NT>(L, rd, v, r);
+        trsvT_rows<G, NT>(L, rd, v, r);
         if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = v[0];
         xnext[0] = inT ? v[0] : 0.0;
     }
 }
 
+// Eight problems per wavefront where a knot fits a half row AND the batch is more than one wavefront per SIMD at
+// four per wavefront (these kernels hold one wavefront per SIMD): below that the launch is one latency chain per
+// wavefront either way and the narrower group only idles SIMDs (cartpole-1 at B = 4096: 2.0 ms both ways;
+// cartpole-2 at B = 8192: 2.24 -> 1.97 ms per AL_mpc.MPC call).
+template <class Map> constexpr bool half_row() { return Map::NX + Map::NU <= 8; }
+inline bool narrow(int B)
+{
+    const char *force = getenv("DQP_AL_LANE_GROUP");          // testing: "8" / "16" pins the group width
+    if (force && force[0] == '8') return true;
+    if (force && force[0] == '1') return false;
+    return B > 4096;
+}
 template <class Map> int run_newton(const BandP &P, void *stream)
 {
-    hipLaunchKernelGGL(al_banded_newton_kernel<Map>, dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
+    if constexpr (half_row<Map>()) {
+        if (narrow(P.B)) {
+            hipLaunchKernelGGL((al_banded_newton_kernel<Map, 8>), dim3((P.B + 7) / 8), dim3(64), 0, (hipStream_t)stream, P);
+            return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL((al_banded_newton_kernel<Map, 16>), dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 template <class Map> int run_solve(const BandP &P, void *stream)
 {
-    hipLaunchKernelGGL(al_banded_solve_kernel<Map>, dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
+    if constexpr (half_row<Map>()) {
+        if (narrow(P.B)) {
+            hipLaunchKernelGGL((al_banded_solve_kernel<Map, 8>), dim3((P.B + 7) / 8), dim3(64), 0, (hipStream_t)stream, P);
+            return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+        }
+    }
+    hipLaunchKernelGGL((al_banded_solve_kernel<Map, 16>), dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 

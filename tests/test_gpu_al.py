@@ -236,10 +236,11 @@ def test_al_mpc_two_calls_vs_reference(name):
     np.testing.assert_allclose(ctrl.rho_prev.cpu().numpy(), g["rho2"], rtol=0, atol=0)
 
 
+@pytest.mark.parametrize("group", ["16", "8"])       # lanes per problem of the block-tridiagonal kernels (8: nt <= 8 models)
 @pytest.mark.parametrize("name,robot", [("CFG3_cartpole1l_T20_b4", "cartpole1l"), ("CFG5_cartpole2l_T5_b4", "cartpole2l"),
                                         ("CFG4_rexquadrotor_T30_b4", "rexquadrotor"),
                                         ("CFG4_rexquadrotor_T6_b4", "rexquadrotor")])
-def test_al_mpc_cartpole_vs_reference(name, robot):
+def test_al_mpc_cartpole_vs_reference(name, robot, group, monkeypatch):
     """BASELINE config 3 (cartpole-1, n 4, m 1, T 20), the config-5 robot (cartpole-2, n 6, T 5) and
     config 4 (quadrotor, n 12, m 4, T 30: nz = 480, and a T = 6 case)
     through AL_mpc.MPC with the DEVICE dynamics registry, against the reference's AL_mpc.MPC run on
@@ -248,6 +249,7 @@ def test_al_mpc_cartpole_vs_reference(name, robot):
     (states reach +-pi, controls +-100); multipliers rtol 1e-5 / atol 1e-5; rho exact."""
     from diff_qp_mpc_amd import AL_mpc, al_utils
     from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    monkeypatch.setenv("DQP_AL_LANE_GROUP", group)
     g = load(name)
     B, T = g["in_Qd"].shape[:2]
     dyn = DeviceDynamics(robot, dt=float(g["dt"]))
@@ -350,9 +352,10 @@ def test_config4_full_size_properties():
     np.testing.assert_allclose(ctrl.lamda_prev[:4].cpu().numpy(), g["lam1"], rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("group", ["16", "8"])
 @pytest.mark.parametrize("robot,T", [("pendulum_euler", 20), ("cartpole1l", 20), ("cartpole2l", 5), ("pendulum_dx", 10),
                                      ("pendulum1l", 3), ("rexquadrotor", 30), ("rexquadrotor", 4)])
-def test_banded_newton_step_vs_dense_oracle(robot, T):
+def test_banded_newton_step_vs_dense_oracle(robot, T, group, monkeypatch):
     """dqp_al_banded_newton_step (block-tridiagonal Cholesky, every knot in registers) against the
     reference's dense formulation restated in numpy (oracle/al_oracle.py: dense constraint Jacobian,
     H = diag(Q) + rho Jc^T Jc, dense Cholesky solve) with the device model's own Jacobians: the same
@@ -361,6 +364,7 @@ def test_banded_newton_step_vs_dense_oracle(robot, T):
     import ctypes
     from diff_qp_mpc_amd import _lib, al_utils
     from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    monkeypatch.setenv("DQP_AL_LANE_GROUP", group)      # one problem per 16-lane row, or per half row (nt <= 8)
     lib = _lib.load()
     dyn = DeviceDynamics(robot)
     n, m, nt = dyn.n_state, dyn.n_ctrl, dyn.n_state + dyn.n_ctrl
@@ -464,13 +468,15 @@ class _UserModule(torch.nn.Module):
         return self._d.jac(x, u)
 
 
+@pytest.mark.parametrize("group", ["16", "8"])
 @pytest.mark.parametrize("name,robot", [("CFG4_rexquadrotor_T30_b4", "rexquadrotor"), ("CFG4_rexquadrotor_T6_b4", "rexquadrotor"),
                                         ("CFG3_cartpole1l_T20_b4", "cartpole1l")])
-def test_al_mpc_user_dynamics_module_banded(name, robot):
+def test_al_mpc_user_dynamics_module_banded(name, robot, group, monkeypatch):
     """AL_mpc.MPC with a caller-supplied dynamics module (not a DeviceDynamics): from nz > 128 on its own
     Jacobians go to dqp_al_banded_newton_step_jac (config 4: nz = 480, beyond the dense Newton step).  Against
     the reference's AL_mpc.MPC fixtures (cold call, gradients, warm-started call); the cartpole case (nz = 100)
     forces the banded path below the threshold and must agree with the same fixtures too."""
+    monkeypatch.setenv("DQP_AL_LANE_GROUP", group)
     from diff_qp_mpc_amd import AL_mpc, al_utils
     g = load(name)
     B, T = g["in_Qd"].shape[:2]
