@@ -699,10 +699,11 @@ template <int TPI> __device__ __forceinline__ double group_sum(double v)
     return v;
 }
 
-template <class Map, int TPI>
+template <class Map, int TPI, int TMAX>
 __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
 {
     constexpr int n = Map::NX, m = Map::NU, nt = n + m, ZS = nt | 1;
+    constexpr int EPL = (TMAX * nt + TPI - 1) / TPI;       // elements of the (T, nt) arrays per lane, T <= TMAX
     extern __shared__ double lsg_lds[];
     const int T = P.T, neq = T * n, ncon = neq + 2 * T * m, nzq = T * nt;
     const int nc = P.ncand > 0 ? P.ncand : 1;
@@ -716,9 +717,9 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
     const double rho = P.rho[b];
     double *zb = lsg_lds + (size_t)grp * T * ZS;
     // ---- the problem, once: element e = r + TPI i of the (T, nt) arrays
-    double ex[nt], eu[nt], eq[nt], el[nt], lu[nt], ll[nt], hi[nt], lo[nt];
+    double ex[EPL], eu[EPL], eq[EPL], el[EPL], lu[EPL], ll[EPL], hi[EPL], lo[EPL];
 #pragma unroll
-    for (int i = 0; i < nt; ++i) {
+    for (int i = 0; i < EPL; ++i) {
         const int e = r + TPI * i, ec = e < nzq ? e : 0, t = ec / nt, j = ec - t * nt;
         const bool ok = e < nzq;
         ex[i] = ok ? xu[ec] : 0.0; eu[i] = (ok && P.ncand > 0) ? up[ec] : 0.0;
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
         const double step = P.ncand > 0 ? (double)exp2f(-(float)k) : 0.0;    // float steps, as the reference
         double acc = 0.0;
 #pragma unroll
-        for (int i = 0; i < nt; ++i) {
+        for (int i = 0; i < EPL; ++i) {
             const int e = r + TPI * i;
             if (e < nzq) {
                 const int t = e / nt, j = e - t * nt;
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
             const double sb = (double)exp2f(-(float)arg);
             double *xw = P.xu_w + b * (long long)nzq;
 #pragma unroll
-            for (int i = 0; i < nt; ++i) {
+            for (int i = 0; i < EPL; ++i) {
                 const int e = r + TPI * i;
                 if (e < nzq) xw[e] = fma(sb, eu[i], ex[i]);
             }
@@ -796,7 +797,7 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
     }
 }
 
-template <class Map, int TPI> int launch_ls_group(const LsAP &P, hipStream_t st)
+template <class Map, int TPI, int TMAX = TPI> int launch_ls_group(const LsAP &P, hipStream_t st)
 {
     constexpr int ZS = (Map::NX + Map::NU) | 1, G = 256 / TPI;
     const size_t lds = (size_t)G * P.T * ZS * sizeof(double);
@@ -804,12 +805,14 @@ template <class Map, int TPI> int launch_ls_group(const LsAP &P, hipStream_t st)
     // at least ~2 wavefronts per SIMD where the batch alone does not give them: split the candidates
     unsigned split = 1;
     if (P.ncand > 1) while (split < 4 && (unsigned long long)blocks * 4 * split < 2048) split *= 2;
-    hipLaunchKernelGGL((al_ls_group_kernel<Map, TPI>), dim3(blocks, split), dim3(256), lds, st, P);
+    hipLaunchKernelGGL((al_ls_group_kernel<Map, TPI, TMAX>), dim3(blocks, split), dim3(256), lds, st, P);
     return (P.xu_w && split == 1 && P.ncand > 0) ? 2 : DQP_OK;     // 2: the selection happened in the kernel
 }
 
 template <class Map> int launch_ls_t(const LsAP &P, hipStream_t st)
 {
+    // the model phase keeps T - 1 lanes of a group busy: four lanes for the shortest horizons (config 5: T = 5)
+    if (P.T <= 5) return launch_ls_group<Map, 4, 5>(P, st);
     if (P.T <= 8) return launch_ls_group<Map, 8>(P, st);
     if (P.T <= 16) return launch_ls_group<Map, 16>(P, st);
     if (P.T <= 32) return launch_ls_group<Map, 32>(P, st);
