@@ -165,121 +165,285 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
 #pragma unroll
     for (int j = 0; j < NX; ++j) { Mprev[j] = 0.0; mu_prev[j] = 0.0; }
 
-    for (int t = 0; t < T; ++t) {
-        // ---- the knot and its successor's state (uniform loads)
-        double z[NT], xn1[NX];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) z[j] = xu[t * NT + j];
-        const bool dynrow = t < T - 1;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) xn1[j] = dynrow ? xu[(t + 1) * NT + j] : 0.0;
-        // ---- column r of J_t = [df/dx df/du] by one forward-mode seed per lane
-        double Jc[NX], mu[NX];
-        if constexpr (is_given<Map>::value) {
-            const int tc = dynrow ? t : 0;
-            const double *fx = P.xnext + (b * (long long)(T - 1) + tc) * NX;
-            const double *jx = P.Jx + (b * (long long)(T - 1) + tc) * NX * NX;
-            const double *ju = P.Ju + (b * (long long)(T - 1) + tc) * NX * NU;
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                const double col = r < NX ? jx[j * NX + r] : ju[j * NU + (inT ? r - NX : 0)];
-                Jc[j] = (dynrow && inT) ? col : 0.0;
-                const double res = dynrow ? xn1[j] - fx[j] : 0.0;
-                mu[j] = dynrow ? lam[t * NX + j] + rho * res : 0.0;
-            }
-        } else {
-            Dual<1> xs[NX], us[NU], out[NX];
-#pragma unroll
-            for (int j = 0; j < NX; ++j) { xs[j] = Dual<1>(z[j]); xs[j].d[0] = (r == j) ? 1.0 : 0.0; }
-#pragma unroll
-            for (int j = 0; j < NU; ++j) { us[j] = Dual<1>(z[NX + j]); us[j].d[0] = (r == NX + j) ? 1.0 : 0.0; }
-            Map::template step<Dual<1>>(xs, us, P.dt, out);
-#pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                Jc[j] = (dynrow && inT) ? out[j].d[0] : 0.0;
-                const double res = dynrow ? xn1[j] - out[j].v : 0.0;                 // x_{t+1} - f(x_t, u_t)
-                mu[j] = dynrow ? lam[t * NX + j] + rho * res : 0.0;
-            }
-        }
-        // ---- gradient element r of this knot, and the diagonal terms of H_tt
-        // (per-lane addresses: one coalesced load each instead of NT predicated ones)
-        const int rr = inT ? r : 0;
-        const double zr = xu[t * NT + rr], qdr = Qd[t * NT + rr], qr = q[t * NT + rr];
-        double g = qdr * zr + qr, dg = qdr;
-#pragma unroll
-        for (int j = 0; j < NX; ++j) g -= Jc[j] * mu[j];
-        {
-            // x rows: + I block of the previous dynamics rows / the x_0 rows; u rows: the box rows
-            const int rx = r < NX ? r : 0, i = (inT && r >= NX) ? r - NX : 0;
-            double prev = 0.0;
-#pragma unroll
-            for (int j = 0; j < NX; ++j) prev = (r == j) ? mu_prev[j] : prev;
-            const double first = lam[(T - 1) * NX + rx] + rho * (zr - x0[rx]);
-            const int row = neq + t * 2 * NU + i;
-            const double rup = zr - P.uu[i], rlo = P.ul[i] - zr;
-            const double lup = lam[row], llo = lam[row + NU];
-            if (r < NX) {
-                g += (t > 0) ? prev : first;
-                dg += rho;
-            } else if (inT) {
-                g += (lup + rho * fmax(rup, 0.0)) - (llo + rho * fmax(rlo, 0.0));
-                dg += rho * ((rup > 0.0 ? 1.0 : 0.0) + (rlo > 0.0 ? 1.0 : 0.0));
-            }
-        }
-        // ---- H_tt row r:  rho J^T J + diag - Gram(M_prev) on the x-x block
-        double H[1][NT], rd[1];
-#pragma unroll
-        for (int c = 0; c < NT; ++c) {
-            double a = 0.0;
-#pragma unroll
-            for (int j = 0; j < NX; ++j) a = fma(Jc[j], Gr::rb(Jc[j], c), a);
-            H[0][c] = rho * a + ((r == c) ? dg : 0.0);
-        }
-        if (t > 0) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-#pragma unroll
-                for (int j = 0; j <= i; ++j) {
-                    const double tot = Gr::sum(Mprev[i] * Mprev[j]);
-                    if (r == i) H[0][j] -= tot;
-                    if (r == j && i != j) H[0][i] -= tot;
+    constexpr bool PRE = NT <= 8;        // small models: prefetched knot inputs, delayed factor stores (below)
+    if constexpr (!PRE) {
+        for (int t = 0; t < T; ++t) {
+            // ---- the knot and its successor's state (uniform loads)
+            double z[NT], xn1[NX];
+    #pragma unroll
+            for (int j = 0; j < NT; ++j) z[j] = xu[t * NT + j];
+            const bool dynrow = t < T - 1;
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) xn1[j] = dynrow ? xu[(t + 1) * NT + j] : 0.0;
+            // ---- column r of J_t = [df/dx df/du] by one forward-mode seed per lane
+            double Jc[NX], mu[NX];
+            if constexpr (is_given<Map>::value) {
+                const int tc = dynrow ? t : 0;
+                const double *fx = P.xnext + (b * (long long)(T - 1) + tc) * NX;
+                const double *jx = P.Jx + (b * (long long)(T - 1) + tc) * NX * NX;
+                const double *ju = P.Ju + (b * (long long)(T - 1) + tc) * NX * NU;
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    const double col = r < NX ? jx[j * NX + r] : ju[j * NU + (inT ? r - NX : 0)];
+                    Jc[j] = (dynrow && inT) ? col : 0.0;
+                    const double res = dynrow ? xn1[j] - fx[j] : 0.0;
+                    mu[j] = dynrow ? lam[t * NX + j] + rho * res : 0.0;
+                }
+            } else {
+                Dual<1> xs[NX], us[NU], out[NX];
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) { xs[j] = Dual<1>(z[j]); xs[j].d[0] = (r == j) ? 1.0 : 0.0; }
+    #pragma unroll
+                for (int j = 0; j < NU; ++j) { us[j] = Dual<1>(z[NX + j]); us[j].d[0] = (r == NX + j) ? 1.0 : 0.0; }
+                Map::template step<Dual<1>>(xs, us, P.dt, out);
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    Jc[j] = (dynrow && inT) ? out[j].d[0] : 0.0;
+                    const double res = dynrow ? xn1[j] - out[j].v : 0.0;                 // x_{t+1} - f(x_t, u_t)
+                    mu[j] = dynrow ? lam[t * NX + j] + rho * res : 0.0;
                 }
             }
-        }
-#pragma unroll
-        for (int c = 0; c < NT; ++c) H[0][c] = inT ? H[0][c] : ((r == c) ? 1.0 : 0.0);
-        if (!chol_g<G, NT>(H, rd, r) && bad == 0) bad = t + 1;
-        // ---- right-hand side: y_t = L_tt^-1 (-g_t - L_{t,t-1} y_{t-1})
-        double y[1] = {inT ? -g : 0.0};
-        if (t > 0) {
-#pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                const double tot = Gr::sum(Mprev[i] * yprev[0]);
-                if (r == i) y[0] -= tot;
+            // ---- gradient element r of this knot, and the diagonal terms of H_tt
+            // (per-lane addresses: one coalesced load each instead of NT predicated ones)
+            const int rr = inT ? r : 0;
+            const double zr = xu[t * NT + rr], qdr = Qd[t * NT + rr], qr = q[t * NT + rr];
+            double g = qdr * zr + qr, dg = qdr;
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) g -= Jc[j] * mu[j];
+            {
+                // x rows: + I block of the previous dynamics rows / the x_0 rows; u rows: the box rows
+                const int rx = r < NX ? r : 0, i = (inT && r >= NX) ? r - NX : 0;
+                double prev = 0.0;
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) prev = (r == j) ? mu_prev[j] : prev;
+                const double first = lam[(T - 1) * NX + rx] + rho * (zr - x0[rx]);
+                const int row = neq + t * 2 * NU + i;
+                const double rup = zr - P.uu[i], rlo = P.ul[i] - zr;
+                const double lup = lam[row], llo = lam[row + NU];
+                if (r < NX) {
+                    g += (t > 0) ? prev : first;
+                    dg += rho;
+                } else if (inT) {
+                    g += (lup + rho * fmax(rup, 0.0)) - (llo + rho * fmax(rlo, 0.0));
+                    dg += rho * ((rup > 0.0 ? 1.0 : 0.0) + (rlo > 0.0 ? 1.0 : 0.0));
+                }
             }
+            // ---- H_tt row r:  rho J^T J + diag - Gram(M_prev) on the x-x block
+            double H[1][NT], rd[1];
+    #pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                double a = 0.0;
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) a = fma(Jc[j], Gr::rb(Jc[j], c), a);
+                H[0][c] = rho * a + ((r == c) ? dg : 0.0);
+            }
+            if (t > 0) {
+    #pragma unroll
+                for (int i = 0; i < NX; ++i) {
+    #pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        const double tot = Gr::sum(Mprev[i] * Mprev[j]);
+                        if (r == i) H[0][j] -= tot;
+                        if (r == j && i != j) H[0][i] -= tot;
+                    }
+                }
+            }
+    #pragma unroll
+            for (int c = 0; c < NT; ++c) H[0][c] = inT ? H[0][c] : ((r == c) ? 1.0 : 0.0);
+            if (!chol_g<G, NT>(H, rd, r) && bad == 0) bad = t + 1;
+            // ---- right-hand side: y_t = L_tt^-1 (-g_t - L_{t,t-1} y_{t-1})
+            double y[1] = {inT ? -g : 0.0};
+            if (t > 0) {
+    #pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const double tot = Gr::sum(Mprev[i] * yprev[0]);
+                    if (r == i) y[0] -= tot;
+                }
+            }
+            trsv_g<G, NT>(H, rd, y, r);
+            // ---- M_t = L_tt^-1 H_{t+1,t}^T: column j of it is the distributed vector -rho J[j][:]
+            double M[NX];
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                double v[1] = {-rho * Jc[j]};
+                trsv_g<G, NT>(H, rd, v, r);
+                M[j] = inT ? v[0] : 0.0;
+            }
+            // ---- keep the knot's factor rows (banded form) and y_t
+            if (live && inT) {
+                double *o = fac + ((long long)t * NT + r) * C::ROW;
+    #pragma unroll
+                for (int c = 0; c < NT; ++c) o[c] = H[0][c];
+                o[NT] = rd[0];
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) o[NT + 1 + j] = M[j];
+            }
+            if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = y[0];        // y parked in the output
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) { Mprev[j] = M[j]; mu_prev[j] = mu[j]; }
+            yprev[0] = inT ? y[0] : 0.0;
         }
-        trsv_g<G, NT>(H, rd, y, r);
-        // ---- M_t = L_tt^-1 H_{t+1,t}^T: column j of it is the distributed vector -rho J[j][:]
-        double M[NX];
-#pragma unroll
-        for (int j = 0; j < NX; ++j) {
-            double v[1] = {-rho * Jc[j]};
-            trsv_g<G, NT>(H, rd, v, r);
-            M[j] = inT ? v[0] : 0.0;
+    } else {
+        // ---- a knot's inputs.  Small models (nt <= 8, where the registers allow it) load knot t + 1 while knot t
+        // computes and write knot t's factor rows while knot t + 1 computes: a knot was one exposed memory round trip
+        // in front of ~2.5 k instructions, and its stores were in the way of the next knot's loads (vmcnt is in order).
+        const int rr = inT ? r : 0, rx = r < NX ? r : 0, iu = (inT && r >= NX) ? r - NX : 0;
+        double x0r = 0.0, lam_first = 0.0, uur = 0.0, ulr = 0.0;        // knot-independent: loaded once where registers allow
+        if constexpr (PRE) { x0r = x0[rx]; lam_first = lam[(T - 1) * NX + rx]; uur = P.uu[iu]; ulr = P.ul[iu]; }
+        double pz[NT], pxn1[NX], plam[NX], pfx[NX], pcol[NX], pzr, pqd, pq, plu, pll;
+        auto load_knot = [&](int t) {
+            const bool dynrow = t < T - 1;
+    #pragma unroll
+            for (int j = 0; j < NT; ++j) pz[j] = xu[t * NT + j];
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                pxn1[j] = dynrow ? xu[(t + 1) * NT + j] : 0.0;
+                plam[j] = dynrow ? lam[t * NX + j] : 0.0;
+            }
+            if constexpr (is_given<Map>::value) {
+                const int tc = dynrow ? t : 0;
+                const double *fx = P.xnext + (b * (long long)(T - 1) + tc) * NX;
+                const double *jx = P.Jx + (b * (long long)(T - 1) + tc) * NX * NX;
+                const double *ju = P.Ju + (b * (long long)(T - 1) + tc) * NX * NU;
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    pfx[j] = fx[j];
+                    pcol[j] = r < NX ? jx[j * NX + r] : ju[j * NU + (inT ? r - NX : 0)];
+                }
+            }
+            pzr = xu[t * NT + rr]; pqd = Qd[t * NT + rr]; pq = q[t * NT + rr];
+            const int row = neq + t * 2 * NU + iu;
+            plu = lam[row]; pll = lam[row + NU];
+        };
+        double sH[NT], sM[NX], srd = 0.0, sy = 0.0;              // PRE: knot t - 1's factor rows, stored during knot t
+        auto store_knot = [&](int t, const double (&Hrow)[NT], double rdv, const double (&Mrow)[NX], double yv) {
+            if (live && inT) {
+                double *o = fac + ((long long)t * NT + r) * C::ROW;
+    #pragma unroll
+                for (int c = 0; c < NT; ++c) o[c] = Hrow[c];
+                o[NT] = rdv;
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) o[NT + 1 + j] = Mrow[j];
+                P.upd[b * (long long)T * NT + t * NT + r] = yv;        // y parked in the output
+            }
+        };
+        if constexpr (PRE) load_knot(0);
+
+        for (int t = 0; t < T; ++t) {
+            if constexpr (!PRE) {
+                load_knot(t);
+                x0r = x0[rx]; lam_first = lam[(T - 1) * NX + rx]; uur = P.uu[iu]; ulr = P.ul[iu];
+            }
+            // ---- the knot and its successor's state
+            double z[NT], xn1[NX], lamt[NX], fxv[NX], colv[NX];
+    #pragma unroll
+            for (int j = 0; j < NT; ++j) z[j] = pz[j];
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) { xn1[j] = pxn1[j]; lamt[j] = plam[j]; fxv[j] = pfx[j]; colv[j] = pcol[j]; }
+            const double zr = pzr, qdr = pqd, qr = pq, lup = plu, llo = pll;
+            const bool dynrow = t < T - 1;
+            if constexpr (PRE) {
+                if (t + 1 < T) load_knot(t + 1);
+                if (t > 0) store_knot(t - 1, sH, srd, sM, sy);
+            }
+            // ---- column r of J_t = [df/dx df/du] by one forward-mode seed per lane
+            double Jc[NX], mu[NX];
+            if constexpr (is_given<Map>::value) {
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    Jc[j] = (dynrow && inT) ? colv[j] : 0.0;
+                    const double res = dynrow ? xn1[j] - fxv[j] : 0.0;
+                    mu[j] = dynrow ? lamt[j] + rho * res : 0.0;
+                }
+            } else {
+                Dual<1> xs[NX], us[NU], out[NX];
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) { xs[j] = Dual<1>(z[j]); xs[j].d[0] = (r == j) ? 1.0 : 0.0; }
+    #pragma unroll
+                for (int j = 0; j < NU; ++j) { us[j] = Dual<1>(z[NX + j]); us[j].d[0] = (r == NX + j) ? 1.0 : 0.0; }
+                Map::template step<Dual<1>>(xs, us, P.dt, out);
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    Jc[j] = (dynrow && inT) ? out[j].d[0] : 0.0;
+                    const double res = dynrow ? xn1[j] - out[j].v : 0.0;                 // x_{t+1} - f(x_t, u_t)
+                    mu[j] = dynrow ? lamt[j] + rho * res : 0.0;
+                }
+            }
+            // ---- gradient element r of this knot, and the diagonal terms of H_tt
+            double g = qdr * zr + qr, dg = qdr;
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) g -= Jc[j] * mu[j];
+            {
+                // x rows: + I block of the previous dynamics rows / the x_0 rows; u rows: the box rows
+                double prev = 0.0;
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) prev = (r == j) ? mu_prev[j] : prev;
+                const double first = lam_first + rho * (zr - x0r);
+                const double rup = zr - uur, rlo = ulr - zr;
+                if (r < NX) {
+                    g += (t > 0) ? prev : first;
+                    dg += rho;
+                } else if (inT) {
+                    g += (lup + rho * fmax(rup, 0.0)) - (llo + rho * fmax(rlo, 0.0));
+                    dg += rho * ((rup > 0.0 ? 1.0 : 0.0) + (rlo > 0.0 ? 1.0 : 0.0));
+                }
+            }
+            // ---- H_tt row r:  rho J^T J + diag - Gram(M_prev) on the x-x block
+            double H[1][NT], rd[1];
+    #pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                double a = 0.0;
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) a = fma(Jc[j], Gr::rb(Jc[j], c), a);
+                H[0][c] = rho * a + ((r == c) ? dg : 0.0);
+            }
+            if (t > 0) {
+    #pragma unroll
+                for (int i = 0; i < NX; ++i) {
+    #pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        const double tot = Gr::sum(Mprev[i] * Mprev[j]);
+                        if (r == i) H[0][j] -= tot;
+                        if (r == j && i != j) H[0][i] -= tot;
+                    }
+                }
+            }
+    #pragma unroll
+            for (int c = 0; c < NT; ++c) H[0][c] = inT ? H[0][c] : ((r == c) ? 1.0 : 0.0);
+            if (!chol_g<G, NT>(H, rd, r) && bad == 0) bad = t + 1;
+            // ---- right-hand side: y_t = L_tt^-1 (-g_t - L_{t,t-1} y_{t-1})
+            double y[1] = {inT ? -g : 0.0};
+            if (t > 0) {
+    #pragma unroll
+                for (int i = 0; i < NX; ++i) {
+                    const double tot = Gr::sum(Mprev[i] * yprev[0]);
+                    if (r == i) y[0] -= tot;
+                }
+            }
+            trsv_g<G, NT>(H, rd, y, r);
+            // ---- M_t = L_tt^-1 H_{t+1,t}^T: column j of it is the distributed vector -rho J[j][:]
+            double M[NX];
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) {
+                double v[1] = {-rho * Jc[j]};
+                trsv_g<G, NT>(H, rd, v, r);
+                M[j] = inT ? v[0] : 0.0;
+            }
+            // ---- keep the knot's factor rows (banded form) and y_t
+            if constexpr (PRE) {
+    #pragma unroll
+                for (int c = 0; c < NT; ++c) sH[c] = H[0][c];
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) sM[j] = M[j];
+                srd = rd[0]; sy = y[0];
+            } else {
+                store_knot(t, H[0], rd[0], M, y[0]);
+            }
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) { Mprev[j] = M[j]; mu_prev[j] = mu[j]; }
+            yprev[0] = inT ? y[0] : 0.0;
         }
-        // ---- keep the knot's factor rows (banded form) and y_t
-        if (live && inT) {
-            double *o = fac + ((long long)t * NT + r) * C::ROW;
-#pragma unroll
-            for (int c = 0; c < NT; ++c) o[c] = H[0][c];
-            o[NT] = rd[0];
-#pragma unroll
-            for (int j = 0; j < NX; ++j) o[NT + 1 + j] = M[j];
-        }
-        if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = y[0];        // y parked in the output
-#pragma unroll
-        for (int j = 0; j < NX; ++j) { Mprev[j] = M[j]; mu_prev[j] = mu[j]; }
-        yprev[0] = inT ? y[0] : 0.0;
+        if constexpr (PRE) store_knot(T - 1, sH, srd, sM, sy);
     }
     // ---- backward sweep: upd_t = L_tt^-T (y_t - M_t upd_{t+1}[:NX])
     double xnext[1] = {0.0};
