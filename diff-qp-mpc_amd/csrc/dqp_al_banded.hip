@@ -445,17 +445,29 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
         }
         if constexpr (PRE) store_knot(T - 1, sH, srd, sM, sy);
     }
-    // ---- backward sweep: upd_t = L_tt^-T (y_t - M_t upd_{t+1}[:NX])
+    // ---- backward sweep: upd_t = L_tt^-T (y_t - M_t upd_{t+1}[:NX]); knot t - 1's rows are loaded while knot t is
+    // solved (a knot here is a memory round trip in front of nt group sums)
     double xnext[1] = {0.0};
-    for (int t = T - 1; t >= 0; --t) {
+    double pL[NT], pM[NX], prd, pv;
+    auto load_rows = [&](int t) {
         const double *o = fac + ((long long)t * NT + (inT ? r : 0)) * C::ROW;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) pL[c] = o[c];
+        prd = o[NT];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) pM[j] = o[NT + 1 + j];
+        pv = P.upd[b * (long long)T * NT + t * NT + (inT ? r : 0)];
+    };
+    load_rows(T - 1);
+    for (int t = T - 1; t >= 0; --t) {
         double L[1][NT], rd[1], M[NX];
 #pragma unroll
-        for (int c = 0; c < NT; ++c) L[0][c] = inT ? o[c] : 0.0;
-        rd[0] = inT ? o[NT] : 0.0;
+        for (int c = 0; c < NT; ++c) L[0][c] = inT ? pL[c] : 0.0;
+        rd[0] = inT ? prd : 0.0;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) M[j] = inT ? o[NT + 1 + j] : 0.0;
-        double v[1] = {inT ? P.upd[b * (long long)T * NT + t * NT + (inT ? r : 0)] : 0.0};
+        for (int j = 0; j < NX; ++j) M[j] = inT ? pM[j] : 0.0;
+        double v[1] = {inT ? pv : 0.0};
+        if (t > 0) load_rows(t - 1);
         if (t < T - 1) {
 #pragma unroll
             for (int j = 0; j < NX; ++j) v[0] = fma(-M[j], Gr::rb(xnext[0], j), v[0]);
