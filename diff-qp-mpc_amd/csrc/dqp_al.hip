@@ -699,6 +699,16 @@ template <int TPI> __device__ __forceinline__ double group_sum(double v)
     return v;
 }
 
+// A lane group (TPI <= 32 lanes) never spans wavefronts and a wavefront's LDS operations execute in order:
+// the group's writes to its own LDS rows only have to be issued before its reads, which a workgroup-scope fence
+// (an s_waitcnt, no s_barrier) plus a scheduling barrier guarantees -- the four wavefronts of the block do not
+// wait for each other twice per candidate.
+__device__ __forceinline__ void group_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <class Map, int TPI, int TMAX>
 __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
 {
@@ -754,7 +764,7 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
                     acc += lu[i] * vh + ll[i] * vl + 0.5 * rho * (fmax(vh, 0.0) * fmax(vh, 0.0) + fmax(vl, 0.0) * fmax(vl, 0.0));
             }
         }
-        __syncthreads();
+        group_sync();
         if (r < T - 1) {
             double z[nt], xn[n];
 #pragma unroll
@@ -766,7 +776,7 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
                 acc += (0.5 * rho * res + ly[j]) * res;
             }
         }
-        __syncthreads();
+        group_sync();
         acc = group_sum<TPI>(acc);
         if (fold) {             // torch.min over the candidates: NaN wins, else the first minimum
             if (k == 0) { best = acc; arg = 0; isnan_ = acc != acc; }
