@@ -31,9 +31,9 @@ R16N_SIZES = [s for s in R16_SIZES if s[2] > 0] + [
 ]
 
 PLAIN_SOURCES = ["dqp_pdipm.hip", "dqp_mpc.hip", "dqp_al.hip", "dqp_term.hip", "dqp_dyn.hip", "dqp_al_banded.hip",
-                 "dqp_ric.hip"]
+                 "dqp_ric.hip", "dqp_trace.hip"]
 SOURCES = PLAIN_SOURCES + ["dqp_r16.hip", "dqp_r16n.hip", "dqp_dispatch.hip"]
-FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-MD",
          "-mllvm", "-pragma-unroll-threshold=10000000", "-mllvm", "-unroll-threshold=10000000"]
 
 
@@ -94,7 +94,8 @@ def _jobs():
 
 def _object_current(obj, cmd):
     """An object is reused when it was produced by the same command line and is newer than its
-    own source and every header (the per-size objects take minutes; most edits touch one file)."""
+    own source and every header that source includes (the compiler's -MD dependency file; the
+    per-size objects take minutes and most edits touch one file)."""
     stamp = obj + ".cmd"
     if not (os.path.exists(obj) and os.path.exists(stamp)):
         return False
@@ -102,10 +103,17 @@ def _object_current(obj, cmd):
         if f.read() != " ".join(cmd):
             return False
     src = cmd[cmd.index("-c") + 1]
-    deps = [src, os.path.join(os.path.dirname(HERE), "include", "dqp.h")]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    deps = [src]
+    dfile = obj[:-2] + ".d"
+    if os.path.exists(dfile):
+        with open(dfile) as f:
+            words = f.read().replace("\\\n", " ").split()
+        deps += [w for w in words[1:] if w.startswith((CSRC, os.path.dirname(HERE)))]
+    else:
+        deps += [os.path.join(os.path.dirname(HERE), "include", "dqp.h")]
+        deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
     t = os.path.getmtime(obj)
-    return all(os.path.getmtime(d) <= t for d in deps)
+    return all(os.path.exists(d) and os.path.getmtime(d) <= t for d in deps)
 
 
 def build(force=False, verbose=False, max_parallel=None):

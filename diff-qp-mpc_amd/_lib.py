@@ -36,9 +36,11 @@ DQP_FLAG_RIC_GLOBAL_WS = 64
 DQP_FLAG_BACKWARD_CTX = 8
 DQP_FLAG_BATCH_TERMINATION = 16
 DQP_FLAG_HISTORY_ONLY = 32
+DQP_FLAG_STRICT_GET_STEP = 128
 DQP_STATUS_Q_NOT_PD = 1
 DQP_STATUS_A_RANK_DEF = 2
 DQP_MAX_DIM = 64
+DQP_MAX_DIM_LARGE = 512
 
 # every symbol include/dqp.h declares
 SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termination_bytes",
@@ -47,7 +49,8 @@ SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termin
            "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble", "dqp_al_merit",
            "dqp_al_newton_solve_bytes", "dqp_al_newton_solve",
            "dqp_al_outer_update", "dqp_al_banded_factor_bytes", "dqp_al_banded_newton_step", "dqp_al_banded_solve",
-           "dqp_al_banded_newton_step_jac",
+           "dqp_al_banded_newton_step_jac", "dqp_al_lane_group",
+           "dqp_mpc_qp_stepped_workspace_bytes", "dqp_mpc_qp_forward_stepped", "dqp_trace_begin", "dqp_trace_end",
            "dqp_dyn_sizes", "dqp_dyn_step", "dqp_dyn_jacobian", "dqp_dyn_forward_dynamics",
            "dqp_dyn_forward_derivatives")
 DQP_DYN = {"pendulum1l": 1, "cartpole1l": 2, "cartpole2l": 3, "pendulum_euler": 4, "pendulum_dx": 5,
@@ -67,6 +70,12 @@ class dqp_al_dims(ctypes.Structure):
 class dqp_mpc_dims(ctypes.Structure):
     _fields_ = [("nbatch", ctypes.c_int32), ("n_state", ctypes.c_int32), ("n_ctrl", ctypes.c_int32),
                 ("T", ctypes.c_int32), ("has_bounds", ctypes.c_int32), ("dyn_id", ctypes.c_int32)]
+
+
+
+class dqp_trace_record(ctypes.Structure):
+    _fields_ = [("kernel", ctypes.c_char * 248), ("ms", ctypes.c_float), ("reserved", ctypes.c_int32)]
+
 
 _lib = None
 
@@ -147,6 +156,17 @@ def load():
     lib.dqp_al_banded_newton_step_jac.argtypes = [ctypes.POINTER(dqp_al_mpc_dims)] + [_dp] * 15
     lib.dqp_al_banded_solve.restype = ctypes.c_int
     lib.dqp_al_banded_solve.argtypes = [ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int] + [_dp] * 4
+    lib.dqp_al_lane_group.restype = ctypes.c_int
+    lib.dqp_al_lane_group.argtypes = [ctypes.c_int]
+    lib.dqp_mpc_qp_stepped_workspace_bytes.restype = ctypes.c_size_t
+    lib.dqp_mpc_qp_stepped_workspace_bytes.argtypes = [ctypes.POINTER(dqp_mpc_dims)]
+    lib.dqp_mpc_qp_forward_stepped.restype = ctypes.c_int
+    lib.dqp_mpc_qp_forward_stepped.argtypes = ([ctypes.POINTER(dqp_mpc_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 8 +
+                                               [ctypes.c_int32, ctypes.c_int32] + [_dp] * 9)
+    lib.dqp_trace_begin.restype = ctypes.c_int
+    lib.dqp_trace_begin.argtypes = [ctypes.c_int32]
+    lib.dqp_trace_end.restype = ctypes.c_int
+    lib.dqp_trace_end.argtypes = [ctypes.POINTER(dqp_trace_record), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32)]
     i32p = ctypes.POINTER(ctypes.c_int32)
     lib.dqp_dyn_sizes.restype = ctypes.c_int
     lib.dqp_dyn_sizes.argtypes = [ctypes.c_int, i32p, i32p]
@@ -166,3 +186,32 @@ def check(rc, what):
     if rc != DQP_OK:
         msg = load().dqp_error_string(rc).decode()
         raise RuntimeError("diff_qp_mpc_amd: %s failed: %s (code %d)" % (what, msg, rc))
+
+
+class trace:
+    """with _lib.trace(max_launches) as t: ...  -> t.records = [(kernel name, ms)], t.by_kernel() = {name: (count, mean ms)}:
+    HIP-event timing of every kernel launch the library makes inside the block (dqp_trace_begin / dqp_trace_end)."""
+
+    def __init__(self, max_launches=4096):
+        self.cap = int(max_launches)
+        self.records = []
+
+    def __enter__(self):
+        check(load().dqp_trace_begin(self.cap), "dqp_trace_begin")
+        return self
+
+    def __exit__(self, *exc):
+        buf = (dqp_trace_record * self.cap)()
+        n = ctypes.c_int32(0)
+        rc = load().dqp_trace_end(buf, self.cap, ctypes.byref(n))
+        self.records = [(buf[i].kernel.decode(errors="replace"), float(buf[i].ms)) for i in range(min(n.value, self.cap))]
+        if exc[0] is None:
+            check(rc, "dqp_trace_end")
+        return False
+
+    def by_kernel(self):
+        acc = {}
+        for k, ms in self.records:
+            c, t = acc.get(k, (0, 0.0))
+            acc[k] = (c + 1, t + ms)
+        return {k: (c, t / c) for k, (c, t) in acc.items()}

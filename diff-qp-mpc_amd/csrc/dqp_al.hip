@@ -815,7 +815,7 @@ template <class Map, int TPI, int TMAX = TPI> int launch_ls_group(const LsAP &P,
     // at least ~2 wavefronts per SIMD where the batch alone does not give them: split the candidates
     unsigned split = 1;
     if (P.ncand > 1) while (split < 4 && (unsigned long long)blocks * 4 * split < 2048) split *= 2;
-    hipLaunchKernelGGL((al_ls_group_kernel<Map, TPI, TMAX>), dim3(blocks, split), dim3(256), lds, st, P);
+    DQP_LAUNCH((al_ls_group_kernel<Map, TPI, TMAX>), dim3(blocks, split), dim3(256), lds, st, P);
     return (P.xu_w && split == 1 && P.ncand > 0) ? 2 : DQP_OK;     // 2: the selection happened in the kernel
 }
 
@@ -827,7 +827,7 @@ template <class Map> int launch_ls_t(const LsAP &P, hipStream_t st)
     if (P.T <= 16) return launch_ls_group<Map, 16>(P, st);
     if (P.T <= 32) return launch_ls_group<Map, 32>(P, st);
     const long long items = (long long)(P.ncand > 0 ? P.ncand : 1) * P.B;
-    hipLaunchKernelGGL(al_ls_kernel<Map>, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, P);
+    DQP_LAUNCH(al_ls_kernel<Map>, dim3((unsigned)((items + 15) / 16)), dim3(256), 0, st, P);
     return DQP_OK;
 }
 
@@ -906,12 +906,12 @@ int launch_outer(const OutP &P, hipStream_t st)
 {
     const dim3 grid((unsigned)((P.B + 15) / 16)), block(256);
     switch (P.dyn) {
-    case DQP_DYN_PENDULUM1L: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>, grid, block, 0, st, P); break;
-    case DQP_DYN_CARTPOLE1L: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>, grid, block, 0, st, P); break;
-    case DQP_DYN_CARTPOLE2L: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>, grid, block, 0, st, P); break;
-    case DQP_DYN_PENDULUM_EULER: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::PendulumEuler>, grid, block, 0, st, P); break;
-    case DQP_DYN_PENDULUM_DX: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::PendulumDx>, grid, block, 0, st, P); break;
-    case DQP_DYN_REXQUADROTOR: hipLaunchKernelGGL(al_outer_kernel<dqp::dyn::RexQuadrotor>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM1L: DQP_LAUNCH(al_outer_kernel<dqp::dyn::Robot<dqp::dyn::Pendulum1l>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE1L: DQP_LAUNCH(al_outer_kernel<dqp::dyn::Robot<dqp::dyn::Cartpole1l>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE2L: DQP_LAUNCH(al_outer_kernel<dqp::dyn::Robot<dqp::dyn::Cartpole2l>>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_EULER: DQP_LAUNCH(al_outer_kernel<dqp::dyn::PendulumEuler>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_DX: DQP_LAUNCH(al_outer_kernel<dqp::dyn::PendulumDx>, grid, block, 0, st, P); break;
+    case DQP_DYN_REXQUADROTOR: DQP_LAUNCH(al_outer_kernel<dqp::dyn::RexQuadrotor>, grid, block, 0, st, P); break;
     default: return DQP_ERR_BAD_ARG;
     }
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
@@ -964,7 +964,7 @@ int launch(K kernel, const AlP &P, size_t lds, void *stream, int threads = 256)
         hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DQP_ERR_LAUNCH;
-    hipLaunchKernelGGL(kernel, dim3(P.B), dim3(threads), lds, (hipStream_t)stream, P);
+    DQP_LAUNCH(kernel, dim3(P.B), dim3(threads), lds, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
@@ -1016,7 +1016,7 @@ dqp_al_assemble(const dqp_al_mpc_dims *d, const double *Jx, const double *Ju, co
     if (d->nbatch == 0) return DQP_OK;
     if (!Jx || !Ju || !res_c || (gterm && (!lam || !rho))) return DQP_ERR_BAD_ARG;
     AsmP P = {Jx, Ju, lam, res_c, rho, Jc, gterm, d->nbatch, d->n_state, d->n_ctrl, d->T, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(al_assemble_kernel, dim3(P.B), dim3(256), 0, (hipStream_t)stream, P);
+    DQP_LAUNCH(al_assemble_kernel, dim3(P.B), dim3(256), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
@@ -1032,7 +1032,7 @@ dqp_al_merit(const dqp_al_mpc_dims *d, int32_t ncand, const double *xu, const do
     MeritP P = {xu, x_next, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, d->nbatch, d->n_state,
                 d->n_ctrl, d->T, ncand};
     const long long total = (long long)ncand * d->nbatch;
-    hipLaunchKernelGGL(al_merit_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream, P);
+    DQP_LAUNCH(al_merit_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
@@ -1090,7 +1090,7 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
             if (rc != DQP_OK && rc != 2) return rc;
             if (rc != 2) {          // candidates split over several groups: select in a launch of its own
                 SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
-                hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
+                DQP_LAUNCH(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
             }
         }
         return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
@@ -1116,9 +1116,9 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
     if (rc) return rc;
     for (int it = 0; it < n_steps; ++it) {
         LinP Li = {xu, x0, u_lower, u_upper, Jx, Ju, resc, dt, B, n, m, T, dyn_id};
-        hipLaunchKernelGGL(al_linearize_kernel, dim3((unsigned)(((long long)B * T + 255) / 256)), dim3(256), 0, st, Li);
+        DQP_LAUNCH(al_linearize_kernel, dim3((unsigned)(((long long)B * T + 255) / 256)), dim3(256), 0, st, Li);
         AsmP As = {Jx, Ju, lam, resc, rho, Jc, grad, B, n, m, T, Qdiag, q, xu};
-        hipLaunchKernelGGL(al_assemble_kernel, dim3(B), dim3(256), 0, st, As);
+        DQP_LAUNCH(al_assemble_kernel, dim3(B), dim3(256), 0, st, As);
         AlP P = A;
         P.Jc = Jc; P.Qd = Qdiag; P.rho = rho; P.grad = grad; P.update = upd; P.L = L; P.info = info;
         switch ((nz + 15) / 16) {
@@ -1136,7 +1136,7 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
         rc = launch_ls(Lc, st);
         if (rc) return rc;
         SelP Se = {merit, upd, x0, xu, merit_cur, status, fail, info, B, n, nz, 20};
-        hipLaunchKernelGGL(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
+        DQP_LAUNCH(al_select_kernel, dim3(B), dim3(64), 0, st, Se);
     }
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }

@@ -545,33 +545,45 @@ __global__ __launch_bounds__(64) void al_banded_solve_kernel(BandP P)
 // wavefront either way and the narrower group only idles SIMDs (cartpole-1 at B = 4096: 2.0 ms both ways;
 // cartpole-2 at B = 8192: 2.24 -> 1.97 ms per AL_mpc.MPC call).
 template <class Map> constexpr bool half_row() { return Map::NX + Map::NU <= 8; }
+// g_lane_group: 0 = by batch size, 8 / 16 = pinned (dqp_al_lane_group; initial value from DQP_AL_LANE_GROUP, read once)
+static int g_lane_group = -1;
+static int g_simds = 0;
 inline bool narrow(int B)
 {
-    const char *force = getenv("DQP_AL_LANE_GROUP");          // testing: "8" / "16" pins the group width
-    if (force && force[0] == '8') return true;
-    if (force && force[0] == '1') return false;
-    return B > 4096;
+    if (g_lane_group < 0) {
+        const char *force = getenv("DQP_AL_LANE_GROUP");
+        g_lane_group = (force && force[0] == '8') ? 8 : ((force && force[0] == '1') ? 16 : 0);
+    }
+    if (g_lane_group) return g_lane_group == 8;
+    if (!g_simds) {         // four SIMDs per CU, one wavefront of these kernels per SIMD
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+        g_simds = 4 * cus;
+    }
+    return (B + 3) / 4 > g_simds;
 }
 template <class Map> int run_newton(const BandP &P, void *stream)
 {
     if constexpr (half_row<Map>()) {
         if (narrow(P.B)) {
-            hipLaunchKernelGGL((al_banded_newton_kernel<Map, 8>), dim3((P.B + 7) / 8), dim3(64), 0, (hipStream_t)stream, P);
+            DQP_LAUNCH((al_banded_newton_kernel<Map, 8>), dim3((P.B + 7) / 8), dim3(64), 0, (hipStream_t)stream, P);
             return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL((al_banded_newton_kernel<Map, 16>), dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
+    DQP_LAUNCH((al_banded_newton_kernel<Map, 16>), dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 template <class Map> int run_solve(const BandP &P, void *stream)
 {
     if constexpr (half_row<Map>()) {
         if (narrow(P.B)) {
-            hipLaunchKernelGGL((al_banded_solve_kernel<Map, 8>), dim3((P.B + 7) / 8), dim3(64), 0, (hipStream_t)stream, P);
+            DQP_LAUNCH((al_banded_solve_kernel<Map, 8>), dim3((P.B + 7) / 8), dim3(64), 0, (hipStream_t)stream, P);
             return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
         }
     }
-    hipLaunchKernelGGL((al_banded_solve_kernel<Map, 16>), dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
+    DQP_LAUNCH((al_banded_solve_kernel<Map, 16>), dim3((P.B + 3) / 4), dim3(64), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
@@ -679,6 +691,13 @@ dqp_al_banded_newton_step_jac(const dqp_al_mpc_dims *d, const double *xu, const 
     DQP_BAND_SIZES
 #undef X
     return DQP_ERR_TOO_LARGE;
+}
+
+__attribute__((visibility("default"))) int dqp_al_lane_group(int width)
+{
+    if (width != 0 && width != 8 && width != 16) return DQP_ERR_BAD_ARG;
+    g_lane_group = width;
+    return DQP_OK;
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/dqp.h"
+#include "dqp_trace.h"
 
 namespace dqp {
 
@@ -43,6 +44,10 @@ struct KParams {
     // as the finish pass reads it
     double *snap;
     const double *histIn;
+    // caller-driven iterations (dqp_mpc_qp_forward_stepped, stage-wise kernels): iterations itBegin .. itEnd-1 of
+    // maxIter, the equality residual of iteration itBegin read from extRy (B, T n) in the closure's ordering
+    const double *extRy;
+    int itBegin, itEnd;
 };
 
 constexpr int TERM_HDR = 8;   // int32 header words in front of the per-problem best-iteration list
@@ -106,6 +111,8 @@ int r16n_snapshot_doubles(int N, int M, int E);
 bool ric_supported(int n_state, int n_ctrl);
 long long ric_workspace_doubles(int n_state, int n_ctrl, int T);
 int ric_forward(const KParams &P, void *stream);      // 1: no kernel for this (n, m)
+long long ric_stepped_workspace_doubles(int n_state, int n_ctrl, int T, int B);
+int ric_forward_stepped(const KParams &P, void *stream);   // iterations [P.itBegin, P.itEnd), residual from P.extRy
 int ric_backward(const KParams &P, void *stream);
 int ric_snapshot_doubles(int n_state, int n_ctrl, int T);   // iterate snapshot of the batch rule's finish pass
 int ric_finish(const KParams &P, void *stream);

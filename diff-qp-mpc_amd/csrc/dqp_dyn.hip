@@ -135,25 +135,25 @@ inline int grid_for(int N) { const int b = (N + 255) / 256; return b < 4096 ? b 
 
 template <class Map> int run_step(int N, const double *x, const double *u, double dt, double *xn, void *s)
 {
-    hipLaunchKernelGGL(step_kernel<Map>, dim3(grid_for(N)), dim3(256), 0, (hipStream_t)s, N, x, u, dt, xn);
+    DQP_LAUNCH(step_kernel<Map>, dim3(grid_for(N)), dim3(256), 0, (hipStream_t)s, N, x, u, dt, xn);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 template <class Map, int KC>
 int run_jac(int N, const double *x, const double *u, double dt, double *xn, double *Jx, double *Ju, void *s)
 {
-    hipLaunchKernelGGL((jac_kernel<Map, KC>), dim3(grid_for(N)), dim3(256), 0, (hipStream_t)s, N, x, u, dt, xn, Jx, Ju);
+    DQP_LAUNCH((jac_kernel<Map, KC>), dim3(grid_for(N)), dim3(256), 0, (hipStream_t)s, N, x, u, dt, xn, Jx, Ju);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 template <class Model>
 int run_fd(int N, const double *q, const double *qd, const double *tau, const double *h, double *qn, double *qdn, void *s)
 {
-    hipLaunchKernelGGL(fd_kernel<Model>, dim3(grid_for(N)), dim3(256), 0, (hipStream_t)s, N, q, qd, tau, h, qn, qdn);
+    DQP_LAUNCH(fd_kernel<Model>, dim3(grid_for(N)), dim3(256), 0, (hipStream_t)s, N, q, qd, tau, h, qn, qdn);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 template <class Model>
 int run_fdd(int N, const double *q, const double *qd, const double *tau, const double *h, double *const *b, void *s)
 {
-    hipLaunchKernelGGL(fdd_kernel<Model>, dim3(grid_for(N)), dim3(256), 0, (hipStream_t)s, N, q, qd, tau, h,
+    DQP_LAUNCH(fdd_kernel<Model>, dim3(grid_for(N)), dim3(256), 0, (hipStream_t)s, N, q, qd, tau, h,
                        b[0], b[1], b[2], b[3], b[4], b[5]);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }

@@ -14,6 +14,7 @@
 
 #include "../../include/dqp.h"
 #include "dqp_dyn_models.h"
+#include "dqp_trace.h"
 
 namespace {
 
@@ -425,7 +426,7 @@ dqp_mpc_assemble(const dqp_mpc_dims *d, const double *C, const double *c, const 
     const long long nt = P.n + P.m, nz = P.T * nt, neq = (long long)P.T * P.n;
     const long long nineq = P.bounds ? 2LL * P.T * P.m : P.m;
     const long long total = (long long)P.B * (nz * nz + neq * nz + nineq * nz + nz + neq + nineq);
-    hipLaunchKernelGGL(assemble_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, P);
+    DQP_LAUNCH(assemble_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
@@ -444,7 +445,7 @@ dqp_mpc_assemble_backward(const dqp_mpc_dims *d, const double *dQ, const double 
     const long long nt = P.n + P.m;
     const long long total = (long long)P.B * (P.T * nt * nt + P.T * nt + (P.T - 1) * P.n * nt +
                                               (P.T - 1) * P.n + P.n);
-    hipLaunchKernelGGL(assemble_backward_kernel, dim3(grid_for(total)), dim3(256), 0,
+    DQP_LAUNCH(assemble_backward_kernel, dim3(grid_for(total)), dim3(256), 0,
                        (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
@@ -479,16 +480,16 @@ dqp_mpc_line_search(const dqp_mpc_dims *d, int dyn_id, double dt, const double *
     using namespace dqp::dyn;
     switch (dyn_id) {
     case 0:
-#define X(a, b) if (P.n == a && P.m == b) { hipLaunchKernelGGL((line_search_kernel<LinStepT<a, b>>), grid, block, 0, st, P); break; }
+#define X(a, b) if (P.n == a && P.m == b) { DQP_LAUNCH((line_search_kernel<LinStepT<a, b>>), grid, block, 0, st, P); break; }
         DQP_LIN_SIZES
 #undef X
-        hipLaunchKernelGGL(line_search_kernel<LinStep>, grid, block, 0, st, P); break;
-    case DQP_DYN_PENDULUM1L: hipLaunchKernelGGL(line_search_kernel<ModelStep<Robot<Pendulum1l>>>, grid, block, 0, st, P); break;
-    case DQP_DYN_CARTPOLE1L: hipLaunchKernelGGL(line_search_kernel<ModelStep<Robot<Cartpole1l>>>, grid, block, 0, st, P); break;
-    case DQP_DYN_CARTPOLE2L: hipLaunchKernelGGL(line_search_kernel<ModelStep<Robot<Cartpole2l>>>, grid, block, 0, st, P); break;
-    case DQP_DYN_PENDULUM_EULER: hipLaunchKernelGGL(line_search_kernel<ModelStep<PendulumEuler>>, grid, block, 0, st, P); break;
-    case DQP_DYN_PENDULUM_DX: hipLaunchKernelGGL(line_search_kernel<ModelStep<PendulumDx>>, grid, block, 0, st, P); break;
-    case DQP_DYN_REXQUADROTOR: hipLaunchKernelGGL(line_search_kernel<ModelStep<RexQuadrotor>>, grid, block, 0, st, P); break;
+        DQP_LAUNCH(line_search_kernel<LinStep>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM1L: DQP_LAUNCH(line_search_kernel<ModelStep<Robot<Pendulum1l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE1L: DQP_LAUNCH(line_search_kernel<ModelStep<Robot<Cartpole1l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE2L: DQP_LAUNCH(line_search_kernel<ModelStep<Robot<Cartpole2l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_EULER: DQP_LAUNCH(line_search_kernel<ModelStep<PendulumEuler>>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_DX: DQP_LAUNCH(line_search_kernel<ModelStep<PendulumDx>>, grid, block, 0, st, P); break;
+    case DQP_DYN_REXQUADROTOR: DQP_LAUNCH(line_search_kernel<ModelStep<RexQuadrotor>>, grid, block, 0, st, P); break;
     default: return DQP_ERR_BAD_ARG;
     }
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
@@ -518,16 +519,16 @@ dqp_mpc_rollout_backward(const dqp_mpc_dims *d, int dyn_id, double dt, const dou
     using namespace dqp::dyn;
     switch (dyn_id) {
     case 0:
-#define X(a, b) if (P.n == a && P.m == b) { hipLaunchKernelGGL((rollout_backward_kernel<LinStepT<a, b>>), grid, block, 0, st, P); break; }
+#define X(a, b) if (P.n == a && P.m == b) { DQP_LAUNCH((rollout_backward_kernel<LinStepT<a, b>>), grid, block, 0, st, P); break; }
         DQP_LIN_SIZES
 #undef X
-        hipLaunchKernelGGL(rollout_backward_kernel<LinStep>, grid, block, 0, st, P); break;
-    case DQP_DYN_PENDULUM1L: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<Robot<Pendulum1l>>>, grid, block, 0, st, P); break;
-    case DQP_DYN_CARTPOLE1L: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<Robot<Cartpole1l>>>, grid, block, 0, st, P); break;
-    case DQP_DYN_CARTPOLE2L: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<Robot<Cartpole2l>>>, grid, block, 0, st, P); break;
-    case DQP_DYN_PENDULUM_EULER: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<PendulumEuler>>, grid, block, 0, st, P); break;
-    case DQP_DYN_PENDULUM_DX: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<PendulumDx>>, grid, block, 0, st, P); break;
-    case DQP_DYN_REXQUADROTOR: hipLaunchKernelGGL(rollout_backward_kernel<ModelStep<RexQuadrotor>>, grid, block, 0, st, P); break;
+        DQP_LAUNCH(rollout_backward_kernel<LinStep>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM1L: DQP_LAUNCH(rollout_backward_kernel<ModelStep<Robot<Pendulum1l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE1L: DQP_LAUNCH(rollout_backward_kernel<ModelStep<Robot<Cartpole1l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_CARTPOLE2L: DQP_LAUNCH(rollout_backward_kernel<ModelStep<Robot<Cartpole2l>>>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_EULER: DQP_LAUNCH(rollout_backward_kernel<ModelStep<PendulumEuler>>, grid, block, 0, st, P); break;
+    case DQP_DYN_PENDULUM_DX: DQP_LAUNCH(rollout_backward_kernel<ModelStep<PendulumDx>>, grid, block, 0, st, P); break;
+    case DQP_DYN_REXQUADROTOR: DQP_LAUNCH(rollout_backward_kernel<ModelStep<RexQuadrotor>>, grid, block, 0, st, P); break;
     default: return DQP_ERR_BAD_ARG;
     }
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;

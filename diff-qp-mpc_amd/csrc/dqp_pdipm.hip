@@ -459,7 +459,8 @@ __device__ __forceinline__ double true_dyn_res(const KParams &P, double *scratch
         case DQP_DYN_CARTPOLE1L: knot_step<dyn::Robot<dyn::Cartpole1l>>(zs, lane, nt, P.dynDt, fs); break;
         case DQP_DYN_CARTPOLE2L: knot_step<dyn::Robot<dyn::Cartpole2l>>(zs, lane, nt, P.dynDt, fs); break;
         case DQP_DYN_PENDULUM_EULER: knot_step<dyn::PendulumEuler>(zs, lane, nt, P.dynDt, fs); break;
-        default: knot_step<dyn::PendulumDx>(zs, lane, nt, P.dynDt, fs); break;
+        case DQP_DYN_PENDULUM_DX: knot_step<dyn::PendulumDx>(zs, lane, nt, P.dynDt, fs); break;
+        default: __builtin_trap();      // fill_params only lets the models above through
         }
     }
     WSYNC();
@@ -491,6 +492,7 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
     term_zero_acc(P);
     int maxIter = P.maxIter;
     const bool batch = (P.flags & DQP_FLAG_BATCH_TERMINATION) != 0;
+    const bool strict = (P.flags & DQP_FLAG_STRICT_GET_STEP) != 0;
     if (P.cap) {        // pass 2 of the batch rule: only the listed QPs, up to the reference's stop
         if (!term_flagged(P, qp)) return;
         maxIter = min(maxIter, P.cap[0]);
@@ -581,6 +583,10 @@ __global__ __launch_bounds__(WAVE) void qp_forward_kernel(KParams P)
         double dxh, dyt;
         kkt_xy<MAXM>(P, S, rxh, ryt, dz, lane, dxh, dyt);
 
+        // DQP_FLAG_STRICT_GET_STEP: batch.py:211-214 divides by the step; an exactly-zero component makes the
+        // reference's iterate NaN, i.e. the problem keeps the best iterate it has (its history is NaN from here)
+        if (strict && __builtin_amdgcn_ballot_w64(inM && (dz_a == 0.0 || ds_a == 0.0 || dz == 0.0 || ds == 0.0)) != 0)
+            break;
         alpha = fmin(0.999 * wave_min(fmin(step_ratio(z, dz, inM), step_ratio(s, ds, inM))), 1.0);
         xh += alpha * dxh;
         s += alpha * ds;
@@ -705,6 +711,10 @@ int fill_params(const dqp_dims *d, const dqp_opts *o, KParams &P, size_t &lds_by
     if (P.dynId) {
         int32_t n = 0, m = 0;
         if (dqp_dyn_sizes(P.dynId, &n, &m) != DQP_OK) return DQP_ERR_BAD_ARG;
+        // models true_dyn_res evaluates on these one-QP-per-wavefront kernels (the quadrotor runs on the stage-wise ones)
+        if (P.dynId != DQP_DYN_PENDULUM1L && P.dynId != DQP_DYN_CARTPOLE1L && P.dynId != DQP_DYN_CARTPOLE2L &&
+            P.dynId != DQP_DYN_PENDULUM_EULER && P.dynId != DQP_DYN_PENDULUM_DX)
+            return DQP_ERR_BAD_ARG;
         P.dynT = o->dyn_T; P.dynN = n; P.dynM = m; P.dynDt = o->dyn_dt; P.dynX0 = o->dyn_x0;
         if (P.dynT < 2 || P.dynT > WAVE || P.N != P.dynT * (n + m) ||
             (P.E != P.dynT * n && P.E != (P.dynT + 1) * n) || !P.dynX0)
@@ -729,7 +739,7 @@ int launch(K kernel, const KParams &P, size_t lds_bytes, void *stream)
                                 (int)lds_bytes) != hipSuccess)
             return DQP_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(kernel, dim3(P.B), dim3(WAVE), lds_bytes, (hipStream_t)stream, P);
+    DQP_LAUNCH(kernel, dim3(P.B), dim3(WAVE), lds_bytes, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
@@ -983,6 +993,59 @@ dqp_mpc_qp_forward(const dqp_mpc_dims *md, const dqp_opts *opts, const double *C
     if ((rc = term_decide(P, termination, stream)) != DQP_OK) return rc;
     term_bind_pass2(P, termination);
     return kind == MPC_R16N ? r16n_forward(P, stream) : ric_finish(P, stream);
+}
+
+// the stage-wise kernels only, whatever the horizon (the null-space kernels keep their iterate in registers)
+static int stepped_params(const dqp_mpc_dims *md, const dqp_opts *opts, KParams &P)
+{
+    if (!md || md->nbatch < 0 || md->n_state <= 0 || md->n_ctrl <= 0 || md->T < 2 || !md->has_bounds) return DQP_ERR_BAD_ARG;
+    if (!ric_supported(md->n_state, md->n_ctrl)) return DQP_ERR_TOO_LARGE;
+    if (md->T > 200000 || ric_workspace_doubles(md->n_state, md->n_ctrl, md->T) * 8 * 4 > 0x7fffffffLL) return DQP_ERR_TOO_LARGE;
+    P.B = md->nbatch;
+    P.N = md->T * (md->n_state + md->n_ctrl); P.M = 2 * md->T * md->n_ctrl; P.E = md->T * md->n_state;
+    fill_opts(opts, P);
+    P.mn = md->n_state; P.mm = md->n_ctrl; P.mT = md->T;
+    return DQP_OK;
+}
+
+__attribute__((visibility("default"))) size_t dqp_mpc_qp_stepped_workspace_bytes(const dqp_mpc_dims *md)
+{
+    KParams P = {};
+    if (stepped_params(md, nullptr, P) != DQP_OK || md->nbatch <= 0) return 0;
+    return (size_t)ric_stepped_workspace_doubles(P.mn, P.mm, P.mT, P.B) * sizeof(double);
+}
+
+__attribute__((visibility("default"))) int
+dqp_mpc_qp_forward_stepped(const dqp_mpc_dims *md, const dqp_opts *opts, const double *C, const double *c,
+                           const double *F, const double *f, const double *x0, const double *u_lower,
+                           const double *u_upper, const double *ext_ry, int32_t it_begin, int32_t it_end,
+                           double *tau, double *lam, double *nu, double *slack, int32_t *info, double *best_resid,
+                           void *workspace, void *termination, void *stream)
+{
+    KParams P = {};
+    int rc = stepped_params(md, opts, P);
+    if (rc != DQP_OK) return rc;
+    if (P.B == 0) return DQP_OK;
+    if (!C || !c || !F || !f || !x0 || !u_lower || !u_upper || !tau || !lam || !nu || !slack || !workspace)
+        return DQP_ERR_BAD_ARG;
+    if (P.maxIter < 1 || it_begin < 0 || it_end < it_begin || it_end > P.maxIter || it_end - it_begin > 1) return DQP_ERR_BAD_ARG;
+    if (it_end > it_begin && !ext_ry) return DQP_ERR_BAD_ARG;
+    if (it_end == it_begin && it_begin != 0) return DQP_ERR_BAD_ARG;
+    P.mC = C; P.mc = c; P.mF = F; P.mf = f; P.mx0 = x0; P.mul = u_lower; P.muu = u_upper;
+    P.zhat = tau; P.lam = lam; P.nu = nu; P.slack = slack; P.info = info; P.best_resid = best_resid;
+    P.workspace = (double *)workspace;
+    P.extRy = ext_ry; P.itBegin = it_begin; P.itEnd = it_end;
+    const bool batch = (P.flags & DQP_FLAG_BATCH_TERMINATION) != 0;
+    if (batch) {
+        if (!termination || P.maxIter > 64) return DQP_ERR_BAD_ARG;
+        P.eps = opts ? opts->eps : 1e-12;
+        term_bind_pass1(P, termination, ric_snapshot_doubles(P.mn, P.mm, P.mT));
+    }
+    if ((rc = ric_forward_stepped(P, stream)) != DQP_OK) return rc == 1 ? DQP_ERR_TOO_LARGE : rc;
+    if (it_end < P.maxIter || !batch || (P.flags & DQP_FLAG_HISTORY_ONLY)) return DQP_OK;
+    if ((rc = term_decide(P, termination, stream)) != DQP_OK) return rc;
+    term_bind_pass2(P, termination);
+    return ric_finish(P, stream);
 }
 
 __attribute__((visibility("default"))) int

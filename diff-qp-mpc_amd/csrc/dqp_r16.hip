@@ -274,6 +274,7 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
     if (!live) qp = P.B - 1;                     // duplicate the last QP; its stores are masked
     int maxIter = P.maxIter;
     const bool batch = (P.flags & DQP_FLAG_BATCH_TERMINATION) != 0;
+    const bool strict = (P.flags & DQP_FLAG_STRICT_GET_STEP) != 0;
     if (P.cap) {        // pass 2 of the batch rule: only the listed QPs, up to the reference's stop
         maxIter = min(maxIter, P.cap[0]);
         live = live && term_flagged(P, qp);
@@ -444,6 +445,11 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             dsa[s] = (-z[s] - dza[s]) * dinv[s];
             tm = fmax(tm, fmax(-dza[s] * rzv[s], -dsa[s] * rsv[s]));
         }
+        bool zero_step = false;             // DQP_FLAG_STRICT_GET_STEP, see dqp_r16n.hip
+        if (strict) {
+#pragma unroll
+            for (int s = 0; s < SM; ++s) zero_step |= inM[s] && (dza[s] == 0.0 || dsa[s] == 0.0);
+        }
         double alpha = frcp(fmax(row_max(tm), 1.0));                           // min(step, 1)
         if (it == 1) STAMP(P, 11);
         double t3 = 0.0;
@@ -468,6 +474,11 @@ __global__ __launch_bounds__(64) void forward_kernel(KParams P)
             dz[s] = dza[s] + dzc[s];
             ds[s] = fma(-rsc[s] - dzc[s], dinv[s], dsa[s]);
             tm = fmax(tm, fmax(-dz[s] * rzv[s], -ds[s] * rsv[s]));
+        }
+        if (strict) {
+#pragma unroll
+            for (int s = 0; s < SM; ++s) zero_step |= inM[s] && (dz[s] == 0.0 || ds[s] == 0.0);
+            if ((__builtin_amdgcn_ballot_w64(zero_step) >> (lane & 48)) & 0xffffull) done = true;
         }
         __builtin_amdgcn_sched_barrier(0);
         // phase 3 (Gh/At live, T dead): x / y part of the combined direction
@@ -637,7 +648,7 @@ int launch(K kernel, const KParams &P, void *stream)
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return DQP_ERR_LAUNCH;
     const int blocks = (P.B + 3) / 4;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P);
+    DQP_LAUNCH(kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 

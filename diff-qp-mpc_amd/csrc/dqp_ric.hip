@@ -821,6 +821,9 @@ __device__ __forceinline__ double sweep_fwd(const Ctx<C> &K0, double musig)
                 ratio = fmin(ratio, dsl < 0.0 ? -sl * frcp(dsl) : INFINITY);
                 ratio = fmin(ratio, dzu < 0.0 ? -zu * frcp(dzu) : INFINITY);
                 ratio = fmin(ratio, dzl < 0.0 ? -zl * frcp(dzl) : INFINITY);
+                // DQP_FLAG_STRICT_GET_STEP: batch.py:211-214 literally -- an exactly-zero component gives -inf there
+                if ((K.P.flags & DQP_FLAG_STRICT_GET_STEP) && (dsu == 0.0 || dsl == 0.0 || dzu == 0.0 || dzl == 0.0))
+                    ratio = -INFINITY;
             }
         }
         if (t < T - 1) {
@@ -906,7 +909,12 @@ __device__ __forceinline__ void copy_best(const Ctx<C> &K, double *snap)
 #ifndef DQP_RIC_WPE
 #define DQP_RIC_WPE 2
 #endif
-template <class C, bool DYN>
+// DYN: 0 the equality residual is A z - b; 1 a registered model's own step (model_residuals); 2 supplied by the
+// caller, one iteration range [P.itBegin, P.itEnd) per launch, the scalar state of the loop parked behind the workspaces
+// (dqp_mpc_qp_forward_stepped)
+enum { RES_LINEAR = 0, RES_MODEL = 1, RES_CALLER = 2 };
+constexpr int STEP_STATE = 8;      // doubles per problem slot
+template <class C, int DYN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE, DQP_RIC_WPE))) void forward_kernel(KParams P, int T)
 {
     constexpr int NX = C::NX, NU = C::NU, NT = C::NT;
@@ -953,7 +961,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
     const int nineq = 2 * T * NU;
     int status = DQP_STATUS_OK;
 
+    constexpr bool STEPPED = DYN == RES_CALLER;
+    const int it0 = STEPPED ? P.itBegin : 0, it1 = STEPPED ? min(P.itEnd, maxIter) : maxIter;
+    double *stp = STEPPED ? P.workspace + (long long)gridDim.x * 4 * L.total + slot * STEP_STATE : nullptr;
+
     // ---- initial point (batch.py:60-86)
+    if (!STEPPED || it0 == 0) {
     if (!factor<C>(K, true, false)) status = DQP_STATUS_Q_NOT_PD;
     sweep_back<C, INIT>(K, 0.0);
     sweep_fwd<C, INIT>(K, 0.0);
@@ -971,14 +984,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
             if (mz < 0.0) { w[L.ZU + i] -= mz - 1.0; w[L.ZL + i] -= mz - 1.0; }
         }
     }
+    }
 
     double best = INFINITY;
     bool have_best = false, done = false;
     int nNot = 0, iters = 0, best_it = 0;
-    for (int it = 0; it < maxIter; ++it) {
+    if (STEPPED && it0 > 0) {       // the loop's scalars as the previous launch left them
+        best = stp[0];
+        const long long pk = (long long)stp[1];
+        have_best = pk & 1; done = pk & 2; status = (int)((pk >> 2) & 3);
+        nNot = (int)stp[2]; iters = (int)stp[3]; best_it = (int)stp[4];
+    }
+    for (int it = it0; it < it1; ++it) {
         double nx2, nz2, ny2, sz;
-        if constexpr (DYN) model_residuals<C>(K);
-        const bool pd = factor_fused<C, DYN>(K, nx2, nz2, ny2, sz);      // residuals + factorisation + affine rhs
+        if constexpr (DYN == RES_MODEL) model_residuals<C>(K);
+        if constexpr (STEPPED) {    // the caller's dyn_res(x) of this iterate, closure ordering = this layout's
+            const double *ery = P.extRy + qp * (long long)(T * NX);
+            for (int i = r; i < (T - 1) * NX; i += 16) w[L.RY + i] = ery[i];
+        }
+        const bool pd = factor_fused<C, DYN != RES_LINEAR>(K, nx2, nz2, ny2, sz);      // residuals + factorisation + affine rhs
         nx2 = row_sum(nx2); nz2 = row_sum(nz2); ny2 = row_sum(ny2); sz = row_sum(sz);
         const double mu = fabs(sz / nineq);
         const double resid = sqrt(nz2) + sqrt(ny2) + sqrt(nx2) + nineq * mu;
@@ -1001,6 +1025,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
         if (!pd && status == DQP_STATUS_OK) status = DQP_STATUS_Q_NOT_PD;
         // affine direction and its step (batch.py:147-163)
         double ra = row_min(sweep_fwd<C, AFFINE>(K, 0.0));
+        const bool zero_step = ra == -INFINITY;     // strict get_step only
         const double alpha_a = fmin(ra, 1.0);
         double t3 = 0.0;
 #pragma unroll 4
@@ -1015,8 +1040,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DQP_RIC_WPE,
         sweep_back<C, CORRECTOR>(K, mu * sig);
         const double rc = row_min(sweep_fwd<C, CORRECTOR>(K, mu * sig));
         const double alpha = fmin(0.999 * rc, 1.0);
+        if (zero_step || rc == -INFINITY) done = true;      // the reference's iterate is NaN from here: keep the best
         if (!done)          // X .. ZL and DX .. DZL are laid out alike: one axpy over the whole iterate
             ew_axpy(w + L.X, w + L.DX, alpha, T * (NT + NX + 4 * NU), r);
+    }
+    if (STEPPED) {
+        if (r == 0) {
+            stp[0] = best;
+            stp[1] = (double)((have_best ? 1 : 0) | (done ? 2 : 0) | (status << 2));
+            stp[2] = nNot; stp[3] = iters; stp[4] = best_it;
+        }
+        if (it1 < maxIter) {        // more iterations to come: hand the current iterate to the caller
+            if (live)
+                for (int i = r; i < T * NT; i += 16) P.zhat[qp * (long long)(T * NT) + i] = w[L.X + i];
+            return;
+        }
     }
     if (P.hist && r == 0 && live) hist_fill(P, qp, iters);
     if (!have_best) {       // max_iter == 0 cannot happen (checked on the host); kept for symmetry
@@ -1134,7 +1172,7 @@ __global__ __launch_bounds__(64) void finish_kernel(KParams P, int T, int nx, in
 template <class C, class Kern> int launch(Kern kernel, const KParams &P, int T, void *stream, size_t lds = 0)
 {
     const int blocks = (P.B + 3) / 4;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P, T);
+    DQP_LAUNCH(kernel, dim3(blocks), dim3(64), lds, (hipStream_t)stream, P, T);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
@@ -1174,12 +1212,26 @@ int ric_forward(const KParams &P, void *stream)
         const bool wsl = !(P.flags & DQP_FLAG_RIC_GLOBAL_WS) && (lds <= 40 * 1024 || (lds <= 64 * 1024 && (P.B + 3) / 4 <= 512)); \
         if constexpr (ric::has_model<Cg>())                                                                           \
             if (P.dynId)                                                                                              \
-                return wsl ? ric::launch<Cl>(ric::forward_kernel<Cl, true>, P, P.mT, stream, lds)                     \
-                           : ric::launch<Cg>(ric::forward_kernel<Cg, true>, P, P.mT, stream);                         \
+                return wsl ? ric::launch<Cl>(ric::forward_kernel<Cl, ric::RES_MODEL>, P, P.mT, stream, lds)                     \
+                           : ric::launch<Cg>(ric::forward_kernel<Cg, ric::RES_MODEL>, P, P.mT, stream);                         \
         if (P.dynId) return 1;                                                                                        \
-        return wsl ? ric::launch<Cl>(ric::forward_kernel<Cl, false>, P, P.mT, stream, lds)                            \
-                   : ric::launch<Cg>(ric::forward_kernel<Cg, false>, P, P.mT, stream);                                \
+        return wsl ? ric::launch<Cl>(ric::forward_kernel<Cl, ric::RES_LINEAR>, P, P.mT, stream, lds)                            \
+                   : ric::launch<Cg>(ric::forward_kernel<Cg, ric::RES_LINEAR>, P, P.mT, stream);                                \
     }
+    DQP_RIC_SIZES
+#undef X
+    return 1;
+}
+
+// caller-driven iterations (dqp_mpc_qp_forward_stepped): always the caller's workspace, STEP_STATE doubles per slot behind it
+long long ric_stepped_workspace_doubles(int n, int m, int T, int B)
+{
+    if (!ric_supported(n, m)) return 0;
+    return (long long)((B + 3) / 4 * 4) * (ric::layout(n, m, T).total + ric::STEP_STATE);
+}
+int ric_forward_stepped(const KParams &P, void *stream)
+{
+#define X(a, b) if (P.mn == a && P.mm == b) return ric::launch<ric::Cfg<a, b>>(ric::forward_kernel<ric::Cfg<a, b>, ric::RES_CALLER>, P, P.mT, stream);
     DQP_RIC_SIZES
 #undef X
     return 1;
@@ -1189,7 +1241,7 @@ int ric_snapshot_doubles(int n, int m, int T) { return ric_supported(n, m) ? T *
 
 int ric_finish(const KParams &P, void *stream)
 {
-    hipLaunchKernelGGL(ric::finish_kernel, dim3(P.B), dim3(64), 0, (hipStream_t)stream, P, P.mT, P.mn, P.mm);
+    DQP_LAUNCH(ric::finish_kernel, dim3(P.B), dim3(64), 0, (hipStream_t)stream, P, P.mT, P.mn, P.mm);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 

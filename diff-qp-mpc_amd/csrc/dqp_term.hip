@@ -158,7 +158,7 @@ void term_bind_pass2(KParams &P, void *term)
 int term_decide(const KParams &P, void *term, void *stream)
 {
     const int blocks = (P.B + 63) / 64;
-    hipLaunchKernelGGL(term_scan_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream,
+    DQP_LAUNCH(term_scan_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream,
                        (const double2 *)term, acc_of(term, P.B, P.maxIter), hdr_of(term, P.B, P.maxIter),
                        P.B, P.maxIter, P.notImprovedLim, P.eps, 1);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
@@ -168,7 +168,7 @@ int term_decide(const KParams &P, void *term, void *stream)
 int term_local_masks(const KParams &P, void *term, unsigned long long *masks, void *stream)
 {
     const int blocks = (P.B + 63) / 64;
-    hipLaunchKernelGGL(term_scan_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream,
+    DQP_LAUNCH(term_scan_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream,
                        (const double2 *)term, acc_of(term, P.B, P.maxIter), hdr_of(term, P.B, P.maxIter),
                        P.B, P.maxIter, P.notImprovedLim, P.eps, 0);
     if (hipMemcpyAsync(masks, acc_of(term, P.B, P.maxIter), 3 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
@@ -180,7 +180,7 @@ int term_local_masks(const KParams &P, void *term, unsigned long long *masks, vo
 // multi-device form, step 2: the rule on the combined masks -> I* of this shard's header
 int term_decide_global(const KParams &P, void *term, const unsigned long long *masks, void *stream)
 {
-    hipLaunchKernelGGL(term_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, masks,
+    DQP_LAUNCH(term_decide_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, masks,
                        hdr_of(term, P.B, P.maxIter), P.maxIter, P.notImprovedLim);
     return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }

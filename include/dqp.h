@@ -28,11 +28,17 @@
 extern "C" {
 #endif
 
-#define DQP_VERSION 212 /* 0.2.1x: dqp_mpc_qp_backward takes C and F, dqp_mpc_dims.dyn_id, dqp_mpc_qp_termination_bytes,
+#define DQP_VERSION 300 /* 0.3.0: DQP_FLAG_STRICT_GET_STEP, dqp_mpc_qp_forward_stepped (caller-supplied equality
+                           residual, one PDIPM iteration range per call), dqp_trace_begin / dqp_trace_end, DQP_MAX_DIM_LARGE
+                           (blocked dense kernels above DQP_MAX_DIM);
+                           0.2.1x: dqp_mpc_qp_backward takes C and F, dqp_mpc_dims.dyn_id, dqp_mpc_qp_termination_bytes,
                            dqp_term_local_masks + dqp_qp_forward_finish,
                            dqp_al_newton_solve_bytes(dims, banded); 212: DQP_FLAG_RIC_GLOBAL_WS, smaller
                            dqp_mpc_qp_workspace_bytes of the stage-wise kernels */
 #define DQP_MAX_DIM 64
+#define DQP_MAX_DIM_LARGE 512 /* dqp_qp_forward / dqp_qp_backward above DQP_MAX_DIM: one QP per workgroup, matrices
+                                 blocked through LDS (csrc/dqp_big.hip); the reference's prof-linear.py sizes
+                                 (nz = nineq up to 500, prof-linear.py:38-46) */
 
 enum {
     DQP_OK = 0,
@@ -82,6 +88,16 @@ enum {
 #define DQP_FLAG_RIC_GLOBAL_WS 64u  /* testing: dqp_mpc_qp_forward's stage-wise kernels keep their iterates
                                       and factors in the caller's workspace even where they would
                                       fit in LDS (the path long horizons take)                  */
+
+#define DQP_FLAG_STRICT_GET_STEP 128u /* forward: batch.py:211-214 literally.  The reference's QPFunction solver computes the
+                                      step ratios as -v/dv with no guard: a step component that is exactly 0.0 gives
+                                      -inf, alpha = -inf, the iterate turns NaN and the problem keeps the best iterate
+                                      it had (its history is NaN from there on).  Its DenseQPFunction solver guards
+                                      the division (batch_LU.py:203-214), and so do these kernels by default.  With
+                                      this flag a problem whose affine or combined step has an exactly-zero slack or
+                                      multiplier component is frozen the way the reference's NaN freezes it.  Which
+                                      problems meet an exact zero depends on the arithmetic order, so this reproduces
+                                      the reference's behaviour class, not its bit pattern.       */
 
 typedef struct dqp_dims {
     int32_t nbatch;
@@ -267,6 +283,28 @@ int dqp_mpc_qp_backward(const dqp_mpc_dims *dims, const dqp_opts *opts, const do
                         double *dx0, int32_t *info, void *workspace, void *stream);
 
 /*
+ * dqp_mpc_qp_forward for a dynamics model the library cannot evaluate (a caller's torch module):
+ * the reference passes its PDIPM a Python closure for the equality residual and calls it once per iteration on
+ * the current iterate (qp_wrapper.py:309,316 -> batch_LU.py:97: ry = dyn_res(x)).  Here the caller drives the
+ * iterations: a call runs ONE PDIPM iteration (it_end == it_begin + 1) of the stage-wise kernels with
+ * `ext_ry` (B, T n_state) as the equality residual of the current iterate, in the closure's ordering
+ * [f(x_t,u_t) - x_{t+1} (t < T-1) ; x_0 - x0] (qp_wrapper.py:326-345; the last n_state entries are recomputed on
+ * chip).  The call it_begin == it_end == 0 only computes the starting point (batch_LU.py:60-86); it_begin == 0,
+ * it_end == 1 computes it and runs iteration 0 on ext_ry -- for callers that know the starting iterate.  After every call `tau`
+ * holds the CURRENT iterate (B, T, n_state+n_ctrl), on which the caller evaluates its model for the next call; the
+ * call with it_end == opts->max_iter finishes as dqp_mpc_qp_forward does (batch rule included) and leaves the
+ * returned best iterate and its multipliers in tau, lam, nu, slack.  All solver state between calls lives in
+ * `workspace` (dqp_mpc_qp_stepped_workspace_bytes: always the caller's buffer) and `termination`.
+ * Shapes: compiled (n_state, n_ctrl) pairs with n_state + n_ctrl <= 16.
+ */
+size_t dqp_mpc_qp_stepped_workspace_bytes(const dqp_mpc_dims *dims);
+int dqp_mpc_qp_forward_stepped(const dqp_mpc_dims *dims, const dqp_opts *opts, const double *C, const double *c,
+                               const double *F, const double *f, const double *x0, const double *u_lower,
+                               const double *u_upper, const double *ext_ry, int32_t it_begin, int32_t it_end,
+                               double *tau, double *lam, double *nu, double *slack, int32_t *info,
+                               double *best_resid, void *workspace, void *termination, void *stream);
+
+/*
  * Replaces: qp_wrapper.MPC.line_search with its rollouts and cost evaluations
  * (qpth/qp_wrapper.py:417-436, 598-611, 690-692; ~60 torch ops and one host sync per round): backtracking
  * on the TRUE rollout cost, alpha in {1, decay, decay^2, ...}, per trajectory, in one launch.
@@ -422,6 +460,11 @@ int dqp_al_banded_newton_step_jac(const dqp_al_mpc_dims *dims, const double *xu,
                                   const double *Jx, const double *Ju, double *update, void *factor,
                                   int32_t *info, void *stream);
 
+/* Testing / A-B runs: pins how many lanes a problem of the block-tridiagonal kernels occupies (8: two problems per
+ * 16-lane DPP row where n_state + n_ctrl <= 8; 16: one per row; 0: chosen from the batch size and the device's CU
+ * count, the default).  The environment variable DQP_AL_LANE_GROUP=8|16 sets the initial value (read once). */
+int dqp_al_lane_group(int width);
+
 /* ----------------------------------------------------------------- device dynamics registry */
 
 /*
@@ -479,6 +522,21 @@ int dqp_dyn_forward_derivatives(int id, int32_t n, const double *q, const double
                                 const double *tau, const double *h, double *q_jac_q,
                                 double *q_jac_qdot, double *q_jac_tau, double *qdot_jac_q,
                                 double *qdot_jac_qdot, double *qdot_jac_tau, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-launch timing of the library's own kernels (bench.py's roofline figures, tools/).  Between
+ * dqp_trace_begin and dqp_trace_end every kernel launch of this library is bracketed by a pair of HIP
+ * events recorded on the launch stream; dqp_trace_end waits for them and returns one record per
+ * launch, in launch order.  The one place the library owns anything: the event pool lives from begin to
+ * end.  Not for use under stream capture.  Single host thread.
+ */
+typedef struct dqp_trace_record {
+    char kernel[248];   /* demangled kernel name, truncated */
+    float ms;           /* hipEventElapsedTime between the two events of this launch */
+    int32_t reserved;
+} dqp_trace_record;
+int dqp_trace_begin(int32_t max_launches);      /* launches beyond max_launches are not recorded */
+int dqp_trace_end(dqp_trace_record *out, int32_t capacity, int32_t *count);  /* out: HOST memory */
 
 #ifdef __cplusplus
 }

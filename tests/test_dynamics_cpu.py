@@ -22,22 +22,32 @@ GOLDEN = os.path.join(HERE, "golden")
 IDS = {"pendulum1l": 1, "cartpole1l": 2, "cartpole2l": 3, "pendulum_euler": 4, "pendulum_dx": 5, "rexquadrotor": 6}
 
 
-@pytest.fixture(scope="module")
-def hostlib():
+def build_hostlib():
+    """tests/host/dyn_host.cpp -> tests/host/_build/libdyn_host.so (host compile of the model templates); None
+    without hipcc and without a prebuilt library."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
     out = os.path.join(HERE, "host", "_build")
-    os.makedirs(out, exist_ok=True)
     so = os.path.join(out, "libdyn_host.so")
     src = os.path.join(HERE, "host", "dyn_host.cpp")
     hdr = os.path.join(os.path.dirname(HERE), "diff-qp-mpc_amd", "csrc", "dqp_dyn_models.h")
-    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    stale = not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr))
+    if stale:
+        if not os.path.exists(hipcc):
+            return None
+        os.makedirs(out, exist_ok=True)
         subprocess.check_call([hipcc, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared",
                                "-ffp-contract=off", "-o", so, src])
     lib = ctypes.CDLL(so)
     lib.dyn_host_jac.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_double] + \
         [ctypes.c_void_p] * 3
+    return lib
+
+
+@pytest.fixture(scope="module")
+def hostlib():
+    lib = build_hostlib()
+    if lib is None:
+        pytest.skip("hipcc not available")
     return lib
 
 

@@ -26,6 +26,19 @@ def load(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
 
+def _pin_lane_group(group):
+    """one problem per 16-lane DPP row ("16") or per half row ("8", nt <= 8) in the block-tridiagonal kernels"""
+    from diff_qp_mpc_amd import _lib
+    assert _lib.load().dqp_al_lane_group(int(group)) == 0
+
+
+@pytest.fixture(autouse=True)
+def _auto_lane_group():
+    yield
+    from diff_qp_mpc_amd import _lib
+    _lib.load().dqp_al_lane_group(0)
+
+
 def dev(a, grad=False):
     t = torch.tensor(np.asarray(a), dtype=torch.float64, device="cuda")
     return t.requires_grad_() if grad else t
@@ -249,7 +262,7 @@ def test_al_mpc_cartpole_vs_reference(name, robot, group, monkeypatch):
     (states reach +-pi, controls +-100); multipliers rtol 1e-5 / atol 1e-5; rho exact."""
     from diff_qp_mpc_amd import AL_mpc, al_utils
     from diff_qp_mpc_amd.dynamics import DeviceDynamics
-    monkeypatch.setenv("DQP_AL_LANE_GROUP", group)
+    _pin_lane_group(group)
     g = load(name)
     B, T = g["in_Qd"].shape[:2]
     dyn = DeviceDynamics(robot, dt=float(g["dt"]))
@@ -364,7 +377,7 @@ def test_banded_newton_step_vs_dense_oracle(robot, T, group, monkeypatch):
     import ctypes
     from diff_qp_mpc_amd import _lib, al_utils
     from diff_qp_mpc_amd.dynamics import DeviceDynamics
-    monkeypatch.setenv("DQP_AL_LANE_GROUP", group)      # one problem per 16-lane row, or per half row (nt <= 8)
+    _pin_lane_group(group)      # one problem per 16-lane row, or per half row (nt <= 8)
     lib = _lib.load()
     dyn = DeviceDynamics(robot)
     n, m, nt = dyn.n_state, dyn.n_ctrl, dyn.n_state + dyn.n_ctrl
@@ -476,7 +489,7 @@ def test_al_mpc_user_dynamics_module_banded(name, robot, group, monkeypatch):
     Jacobians go to dqp_al_banded_newton_step_jac (config 4: nz = 480, beyond the dense Newton step).  Against
     the reference's AL_mpc.MPC fixtures (cold call, gradients, warm-started call); the cartpole case (nz = 100)
     forces the banded path below the threshold and must agree with the same fixtures too."""
-    monkeypatch.setenv("DQP_AL_LANE_GROUP", group)
+    _pin_lane_group(group)
     from diff_qp_mpc_amd import AL_mpc, al_utils
     g = load(name)
     B, T = g["in_Qd"].shape[:2]

@@ -147,3 +147,62 @@ def test_broke_down_detector():
     assert not broke_down(o2["resid_hist"], o2["iters"]).any()
     changed = np.abs(o["slack"] - o2["slack"]).max(1) > 1e-9
     assert not (changed & ~bd).any()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# oracle/al_solve_oracle.py (numpy restatement of one AL_mpc.MPC call) against the reference's AL_mpc.MPC outputs:
+# x, u are float32 in the reference (AL_mpc.py:319-320) -> rtol 1e-4 / atol 1e-5; multipliers rtol 1e-5 / atol 1e-5
+# (cartpole states reach +-pi and controls +-100); rho exact; gradients rtol 1e-4 / atol 1e-6.
+def _al_step(robot, dt):
+    from oracle import dyn_ref
+    if robot in dyn_ref.ROBOTS:
+        if not dyn_ref.available(robot):
+            pytest.skip("oracle/_ref not built (needs /root/reference; see oracle/Makefile)")
+
+        def step(x, u):
+            fx, fu = dyn_ref.jac_x(robot, x, u, dt)
+            return dyn_ref.step_x(robot, x, u, dt), fx, fu
+        return step
+    from test_dynamics_cpu import IDS, build_hostlib          # host build of the model templates (DYN_*.npz-pinned)
+    lib = build_hostlib()
+    if lib is None:
+        pytest.skip("hipcc not available")
+
+    def step(x, u):
+        x, u = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(u, dtype=np.float64)
+        N, n, m = x.shape[0], x.shape[1], u.shape[1]
+        xn, Jx, Ju = np.empty((N, n)), np.empty((N, n, n)), np.empty((N, n, m))
+        assert lib.dyn_host_jac(IDS[robot], N, x.ctypes.data, u.ctypes.data, dt, xn.ctypes.data, Jx.ctypes.data,
+                                Ju.ctypes.data) == 0
+        return xn, Jx, Ju
+    return step
+
+
+@pytest.mark.parametrize("name,robot", [("CFG3_cartpole1l_T20_b4", "cartpole1l"), ("CFG5_cartpole2l_T5_b4", "cartpole2l"),
+                                        ("CFG4_rexquadrotor_T6_b4", "rexquadrotor")])
+def test_al_solve_oracle_matches_reference(name, robot):
+    from oracle import al_solve_oracle as aso
+    g = load(name)
+    step = _al_step(robot, float(g["dt"]))
+    B, T, nt = g["in_Qd"].shape
+    n = g["in_x0"].shape[1]
+    m = nt - n
+    lam0, rho0 = np.zeros((B, T * n + 2 * T * m)), np.ones((B, 1))
+    o1 = aso.al_solve(g["in_x_init"], g["in_u_init"], g["in_x0"], g["in_Qd"], g["in_c"], g["in_u_lower"], g["in_u_upper"],
+                      step, lam0, rho0)
+    np.testing.assert_allclose(o1["x"], g["x1"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(o1["u"], g["u1"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(o1["lam"], g["lam1"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(o1["rho"], g["rho1"])
+    # backward of x.sum() + 2 u.sum() (the generator's loss)
+    gxu = np.concatenate((np.ones((B, T, n)), 2.0 * np.ones((B, T, m))), 2)
+    dQ, dq = aso.backward(o1["L"], o1["xu"], gxu)
+    np.testing.assert_allclose(dQ, g["dC1"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dq, g["dc1"], rtol=1e-4, atol=1e-6)
+    # the warm-started second call starts from the float32 solution of the first (AL_mpc.py:250-251)
+    o2 = aso.al_solve(g["x1"].astype(np.float64), g["u1"].astype(np.float64), g["in_x0"], g["in_Qd"], g["in_c"],
+                      g["in_u_lower"], g["in_u_upper"], step, o1["lam"], o1["rho"], history=o1["history"])
+    np.testing.assert_allclose(o2["x"], g["x2"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(o2["u"], g["u2"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(o2["lam"], g["lam2"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(o2["rho"], g["rho2"])
