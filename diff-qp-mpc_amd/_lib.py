@@ -37,6 +37,7 @@ DQP_FLAG_BACKWARD_CTX = 8
 DQP_FLAG_BATCH_TERMINATION = 16
 DQP_FLAG_HISTORY_ONLY = 32
 DQP_FLAG_STRICT_GET_STEP = 128
+DQP_FLAG_STAGEWISE = 256
 DQP_STATUS_Q_NOT_PD = 1
 DQP_STATUS_A_RANK_DEF = 2
 DQP_MAX_DIM = 64
@@ -50,7 +51,7 @@ SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termin
            "dqp_al_newton_solve_bytes", "dqp_al_newton_solve",
            "dqp_al_outer_update", "dqp_al_banded_factor_bytes", "dqp_al_banded_newton_step", "dqp_al_banded_solve",
            "dqp_al_banded_newton_step_jac", "dqp_al_lane_group",
-           "dqp_mpc_qp_stepped_workspace_bytes", "dqp_mpc_qp_forward_stepped", "dqp_trace_begin", "dqp_trace_end",
+           "dqp_mpc_qp_stepped_workspace_bytes", "dqp_mpc_qp_stepped_termination_bytes", "dqp_mpc_qp_forward_stepped", "dqp_trace_begin", "dqp_trace_end",
            "dqp_dyn_sizes", "dqp_dyn_step", "dqp_dyn_jacobian", "dqp_dyn_forward_dynamics",
            "dqp_dyn_forward_derivatives")
 DQP_DYN = {"pendulum1l": 1, "cartpole1l": 2, "cartpole2l": 3, "pendulum_euler": 4, "pendulum_dx": 5,
@@ -160,6 +161,8 @@ def load():
     lib.dqp_al_lane_group.argtypes = [ctypes.c_int]
     lib.dqp_mpc_qp_stepped_workspace_bytes.restype = ctypes.c_size_t
     lib.dqp_mpc_qp_stepped_workspace_bytes.argtypes = [ctypes.POINTER(dqp_mpc_dims)]
+    lib.dqp_mpc_qp_stepped_termination_bytes.restype = ctypes.c_size_t
+    lib.dqp_mpc_qp_stepped_termination_bytes.argtypes = [ctypes.POINTER(dqp_mpc_dims), ctypes.POINTER(dqp_opts)]
     lib.dqp_mpc_qp_forward_stepped.restype = ctypes.c_int
     lib.dqp_mpc_qp_forward_stepped.argtypes = ([ctypes.POINTER(dqp_mpc_dims), ctypes.POINTER(dqp_opts)] + [_dp] * 8 +
                                                [ctypes.c_int32, ctypes.c_int32] + [_dp] * 9)

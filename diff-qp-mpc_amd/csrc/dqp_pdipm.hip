@@ -904,7 +904,8 @@ static int mpc_params(const dqp_mpc_dims *md, const dqp_opts *opts, KParams &P, 
         int32_t dn = 0, dm = 0;
         if (dqp_dyn_sizes(md->dyn_id, &dn, &dm) != DQP_OK || dn != md->n_state || dm != md->n_ctrl) return DQP_ERR_BAD_ARG;
     }
-    if (!md->dyn_id && r16n_workspace_doubles(d.nz, d.nineq, d.neq) > 0) {
+    const bool stagewise = opts && (opts->flags & DQP_FLAG_STAGEWISE);
+    if (!md->dyn_id && !stagewise && r16n_workspace_doubles(d.nz, d.nineq, d.neq) > 0) {
         dqp_opts o2;
         if (opts) { o2 = *opts; o2.dyn_id = 0; }
         int rc = fill_params(&d, opts ? &o2 : nullptr, P, lds);
@@ -1013,6 +1014,13 @@ __attribute__((visibility("default"))) size_t dqp_mpc_qp_stepped_workspace_bytes
     KParams P = {};
     if (stepped_params(md, nullptr, P) != DQP_OK || md->nbatch <= 0) return 0;
     return (size_t)ric_stepped_workspace_doubles(P.mn, P.mm, P.mT, P.B) * sizeof(double);
+}
+
+__attribute__((visibility("default"))) size_t dqp_mpc_qp_stepped_termination_bytes(const dqp_mpc_dims *md, const dqp_opts *o)
+{
+    KParams P = {};
+    if (!o || !(o->flags & DQP_FLAG_BATCH_TERMINATION) || stepped_params(md, o, P) != DQP_OK || md->nbatch <= 0) return 0;
+    return term_bytes(P.B, P.maxIter, ric_snapshot_doubles(P.mn, P.mm, P.mT));
 }
 
 __attribute__((visibility("default"))) int

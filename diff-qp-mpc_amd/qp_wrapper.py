@@ -207,6 +207,78 @@ class _MPCQP(Function):
         return (*outs, None, None, None, None, None, None)
 
 
+class _MPCQPStepped(Function):
+    """_MPCQP for a dynamics model the library cannot evaluate (a caller's torch module): the reference calls its
+    dyn_res closure once per PDIPM iteration on the current iterate (qp_wrapper.py:309,316 -> batch_LU.py:97).
+    Here: one stage-wise PDIPM iteration per C-ABI call (dqp_mpc_qp_forward_stepped), the module evaluated in
+    between on the iterate the call hands back -- one torch evaluation per iteration, everything else on chip."""
+
+    @staticmethod
+    def supported(B, n_state, n_ctrl, T):
+        dims = _lib.dqp_mpc_dims(B, n_state, n_ctrl, T, 1, 0)
+        return int(_lib.load().dqp_mpc_qp_stepped_workspace_bytes(ctypes.byref(dims))) > 0
+
+    @staticmethod
+    def forward(ctx, C, c, F, f, x0, u_lower, u_upper, n_state, n_ctrl, T, residual):
+        from . import qp as qpmod
+        lib = _lib.load()
+        dev, B, nt = x0.device, x0.shape[0], n_state + n_ctrl
+        cv = lambda t: t.detach().double().contiguous()
+        keep = [cv(C), cv(c), cv(F), cv(f), cv(x0), cv(u_lower).reshape(-1), cv(u_upper).reshape(-1)]
+        if keep[5].numel() != n_ctrl or keep[6].numel() != n_ctrl:
+            raise RuntimeError("u_lower/u_upper must have shape (n_ctrl,) (qp_wrapper.py:677-678)")
+        dims = _lib.dqp_mpc_dims(B, n_state, n_ctrl, T, 1, 0)
+        batch = qpmod.TERMINATION == "batch"
+        max_iter = 20
+        opts = _lib.dqp_opts(1e-12, qpmod.STALL_TOL, max_iter, 3, (_lib.DQP_FLAG_BATCH_TERMINATION if batch else 0) | EXTRA_FLAGS, 0)
+        kw = dict(dtype=torch.float64, device=dev)
+        tau = torch.empty(B, T, nt, **kw)
+        lam = torch.empty(B, 2 * T * n_ctrl, **kw); slack = torch.empty(B, 2 * T * n_ctrl, **kw)
+        nu = torch.empty(B, T * n_state, **kw)
+        info = torch.empty(B, 2, dtype=torch.int32, device=dev)
+        resid = torch.empty(B, **kw)
+        ws = torch.empty(int(lib.dqp_mpc_qp_stepped_workspace_bytes(ctypes.byref(dims))) // 8, **kw)
+        tb = int(lib.dqp_mpc_qp_stepped_termination_bytes(ctypes.byref(dims), ctypes.byref(opts)))
+        term = torch.empty((tb + 7) // 8, **kw) if tb else None
+
+        def call(ry, it0, it1):
+            with torch.cuda.device(dev):
+                rc = lib.dqp_mpc_qp_forward_stepped(ctypes.byref(dims), ctypes.byref(opts), *[_ptr(t) for t in keep], _ptr(ry),
+                                                    it0, it1, _ptr(tau), _ptr(lam), _ptr(nu), _ptr(slack), _ptr(info),
+                                                    _ptr(resid), _ptr(ws), _ptr(term), _stream(dev))
+            _lib.check(rc, "dqp_mpc_qp_forward_stepped")
+
+        with torch.no_grad():
+            call(None, 0, 0)                                    # starting point -> tau
+            for it in range(max_iter):
+                ry = residual(tau.reshape(B, -1).to(x0.dtype)).detach().double().contiguous()
+                call(ry, it, it + 1)                            # the last call leaves the best iterate in tau
+        ctx.dims, ctx.ws = dims, ws
+        ctx.shapes = (C.shape, c.shape, F.shape, f.shape, x0.shape)
+        ctx.dtype = x0.dtype
+        ctx.save_for_backward(tau, lam, nu, slack, keep[0], keep[2])
+        ctx.info, ctx.resid = info, resid
+        return tau.to(x0.dtype)
+
+    @staticmethod
+    def backward(ctx, dtau):
+        lib = _lib.load()
+        tau, lam, nu, slack, C64, F64 = ctx.saved_tensors
+        dev = tau.device
+        kw = dict(dtype=torch.float64, device=dev)
+        need = ctx.needs_input_grad
+        outs = [torch.empty(s, **kw) if need[i] else None for i, s in enumerate(ctx.shapes)]
+        g = dtau.detach().double().contiguous()
+        opts = _lib.dqp_opts(0.0, 0.0, 0, 0, _lib.DQP_FLAG_DENSE_BACKWARD | _lib.DQP_FLAG_STAGEWISE, 0)
+        with torch.cuda.device(dev):
+            rc = lib.dqp_mpc_qp_backward(ctypes.byref(ctx.dims), ctypes.byref(opts), _ptr(C64), _ptr(F64), _ptr(tau), _ptr(lam),
+                                         _ptr(nu), _ptr(slack), _ptr(g), *[_ptr(o) for o in outs],
+                                         ctypes.c_void_p(0), _ptr(ctx.ws), _stream(dev))
+        _lib.check(rc, "dqp_mpc_qp_backward")
+        outs = [None if o is None else o.to(ctx.dtype) for o in outs]
+        return (*outs, None, None, None, None, None, None)
+
+
 class _Rollout(Function):
     """rollout(x0, u, dynamics) as one launch each way (dqp_mpc_line_search with C == NULL;
     dqp_mpc_rollout_backward)."""
@@ -349,6 +421,7 @@ class MPC(Module):
             raise NotImplementedError("add_goal_constraint with a nonzero x_goal is inconsistent in the "
                                       "reference (b uses 0, dyn_res uses x_goal); only x_goal = 0 is supported")
         dyn_res = None
+        stepped = False
         if isinstance(dx, LinDx):
             F = dx.F
             f = dx.f if dx.f is not None else torch.zeros(self.T - 1, self.n_batch, self.n_state,
@@ -360,16 +433,27 @@ class MPC(Module):
             if isinstance(self.dx_true, DeviceDynamics):        # the reference's dyn_res_lam, on chip
                 dyn_res = DynamicsResidual(self.dx_true, x0, self.T, goal_rows=self.add_goal_constraint)
             elif not self.linearised_residual:
-                raise NotImplementedError(
-                    "qp_wrapper.MPC evaluates the true-dynamics residual inside the QP iterations "
-                    "(reference qp_wrapper.py:309,316); that is fused on chip for registered device "
-                    "models only (dynamics.DeviceDynamics).  Pass linearised_residual=True to solve with "
-                    "the residual of the linearised dynamics instead.")
+                stepped = True
         ul = uu = None
         if self.u_upper is not None:
             as_t = lambda v: (torch.full((self.n_ctrl,), float(v), dtype=torch.float64, device=x0.device)
                               if isinstance(v, float) else v.to(x0.device))
             ul, uu = as_t(self.u_lower), as_t(self.u_upper)
+        if stepped:
+            # a caller's dynamics module: its residual is evaluated by torch once per PDIPM iteration, the iteration
+            # itself runs on the stage-wise kernels (dqp_mpc_qp_forward_stepped)
+            if (self.add_goal_constraint or ul is None
+                    or not _MPCQPStepped.supported(self.n_batch, self.n_state, self.n_ctrl, self.T)):
+                raise NotImplementedError(
+                    "qp_wrapper.MPC with a caller-supplied dynamics module evaluates the module's residual once per "
+                    "QP iteration (reference qp_wrapper.py:309,316) around the stage-wise kernels: that needs control "
+                    "bounds, no goal constraint and a compiled (n_state, n_ctrl) pair with n_state + n_ctrl <= 16.  "
+                    "Register the model (dynamics.DeviceDynamics) or pass linearised_residual=True otherwise.")
+            dx_true = self.dx_true
+            tau = _MPCQPStepped.apply(cost.C, cost.c, F, f, x0, ul, uu, self.n_state, self.n_ctrl, self.T,
+                                      lambda z: self.dyn_res(z, dx_true, x0))
+            x_qp, u_qp = tau[..., :self.n_state].transpose(0, 1), tau[..., self.n_state:].transpose(0, 1)
+            return x_qp - x, u_qp - u, (self.compute_cost(tau, cost) if need_cost else None)
         dyn_model = dyn_res.dynamics if isinstance(dyn_res, DynamicsResidual) else None
         if (FUSED_MPC_QP and (dyn_res is None or dyn_model is not None) and not self.add_goal_constraint
                 and ul is not None

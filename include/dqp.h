@@ -99,6 +99,10 @@ enum {
                                       problems meet an exact zero depends on the arithmetic order, so this reproduces
                                       the reference's behaviour class, not its bit pattern.       */
 
+#define DQP_FLAG_STAGEWISE 256u /* dqp_mpc_qp_forward / _backward: take the stage-wise (Riccati) kernels even where a
+                                      null-space instantiation exists for the shape (testing; and the backward of a
+                                      dqp_mpc_qp_forward_stepped solve, whose workspace is the stage-wise one)        */
+
 typedef struct dqp_dims {
     int32_t nbatch;
     int32_t nz;
@@ -298,6 +302,7 @@ int dqp_mpc_qp_backward(const dqp_mpc_dims *dims, const dqp_opts *opts, const do
  * Shapes: compiled (n_state, n_ctrl) pairs with n_state + n_ctrl <= 16.
  */
 size_t dqp_mpc_qp_stepped_workspace_bytes(const dqp_mpc_dims *dims);
+size_t dqp_mpc_qp_stepped_termination_bytes(const dqp_mpc_dims *dims, const dqp_opts *opts);
 int dqp_mpc_qp_forward_stepped(const dqp_mpc_dims *dims, const dqp_opts *opts, const double *C, const double *c,
                                const double *F, const double *f, const double *x0, const double *u_lower,
                                const double *u_upper, const double *ext_ry, int32_t it_begin, int32_t it_end,

@@ -23,24 +23,8 @@ IDS = {"pendulum1l": 1, "cartpole1l": 2, "cartpole2l": 3, "pendulum_euler": 4, "
 
 
 def build_hostlib():
-    """tests/host/dyn_host.cpp -> tests/host/_build/libdyn_host.so (host compile of the model templates); None
-    without hipcc and without a prebuilt library."""
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    out = os.path.join(HERE, "host", "_build")
-    so = os.path.join(out, "libdyn_host.so")
-    src = os.path.join(HERE, "host", "dyn_host.cpp")
-    hdr = os.path.join(os.path.dirname(HERE), "diff-qp-mpc_amd", "csrc", "dqp_dyn_models.h")
-    stale = not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr))
-    if stale:
-        if not os.path.exists(hipcc):
-            return None
-        os.makedirs(out, exist_ok=True)
-        subprocess.check_call([hipcc, "-x", "hip", "--cuda-host-only", "-O2", "-std=c++17", "-fPIC", "-shared",
-                               "-ffp-contract=off", "-o", so, src])
-    lib = ctypes.CDLL(so)
-    lib.dyn_host_jac.argtypes = [ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 2 + [ctypes.c_double] + \
-        [ctypes.c_void_p] * 3
-    return lib
+    from oracle import dyn_host
+    return dyn_host.build()
 
 
 @pytest.fixture(scope="module")

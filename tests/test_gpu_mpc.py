@@ -167,22 +167,47 @@ def test_config2_pendulumdx_vs_reference(tag, kw):
     np.testing.assert_allclose(res[True][2][:, same], g[tag + "_dc"][:, same], rtol=1e-4, atol=1e-6)
 
 
-def test_config2_linearised_residual_is_a_different_problem():
-    """What round 1 silently did (residual of the LINEARISED dynamics inside the QP) does not
-    reproduce the reference on a nonlinear model: the deviation is measured here so that it is on
-    record, and an unregistered dynamics module is refused unless the caller opts in."""
+class _Opaque(torch.nn.Module):
+    """a registered model's map behind a module the solver cannot recognise"""
+
+    def __init__(self, dx):
+        super().__init__()
+        self.dx = dx
+
+    def forward(self, x, u):
+        return self.dx(x, u)
+
+
+@pytest.mark.parametrize("tag,kw", [("single", dict(single_qp_solve=True)), ("sqp3", dict(qp_iter=3))])
+def test_config2_unregistered_module_vs_reference(tag, kw):
+    """A caller's torch dynamics module (not in the device registry): the reference evaluates its residual closure
+    once per PDIPM iteration (qp_wrapper.py:309,316,326-345 -> batch_LU.py:97).  The mirror drives the stage-wise
+    kernels one iteration per call (dqp_mpc_qp_forward_stepped) and evaluates the module in between.  Same golden
+    as the registered-model test (the reference itself, make_golden_cfg2.py), same tolerances: x, u rtol 1e-5 /
+    atol 1e-7; gradients wrt C, c rtol 1e-4 / atol 1e-6 on every sample (the torch line search follows the
+    reference's summation order)."""
     from diff_qp_mpc_amd import qp_wrapper
     g0 = load("CFG2_pendulumdx_T10_b6")
     B, T = g0["x0"].shape[0], 10
     g, dx, C, c, lo, hi = _cfg2_problem(B, T, g0["x0"])
+    ctrl = qp_wrapper.MPC(3, 1, T, u_lower=lo, u_upper=hi, n_batch=B, max_linesearch_iter=5, linesearch_decay=0.2, **kw)
+    x, u = ctrl(dev(g["x0"]), qp_wrapper.QuadCost(C, c), _Opaque(dx), dx.jac)
+    np.testing.assert_allclose(x.detach().cpu().numpy(), g[tag + "_x"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(u.detach().cpu().numpy(), g[tag + "_u"], rtol=1e-5, atol=1e-7)
+    (x.sum() + 2.0 * u.sum()).backward()
+    np.testing.assert_allclose(C.grad.cpu().numpy(), g[tag + "_dC"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(c.grad.cpu().numpy(), g[tag + "_dc"], rtol=1e-4, atol=1e-6)
 
-    class Opaque(torch.nn.Module):          # the same map, but not a registered device model
-        def forward(self, x, u):
-            return dx(x, u)
 
-    args = (dev(g["x0"]), qp_wrapper.QuadCost(C, c), Opaque(), dx.jac)
-    with pytest.raises(NotImplementedError, match="true-dynamics residual"):
-        qp_wrapper.MPC(3, 1, T, u_lower=lo, u_upper=hi, n_batch=B, single_qp_solve=True)(*args)
+def test_config2_linearised_residual_is_a_different_problem():
+    """What round 1 silently did (residual of the LINEARISED dynamics inside the QP) does not
+    reproduce the reference on a nonlinear model: the deviation is measured here so that it is on
+    record (linearised_residual=True is an opt-in extension)."""
+    from diff_qp_mpc_amd import qp_wrapper
+    g0 = load("CFG2_pendulumdx_T10_b6")
+    B, T = g0["x0"].shape[0], 10
+    g, dx, C, c, lo, hi = _cfg2_problem(B, T, g0["x0"])
+    args = (dev(g["x0"]), qp_wrapper.QuadCost(C, c), _Opaque(dx), dx.jac)
     x, u = qp_wrapper.MPC(3, 1, T, u_lower=lo, u_upper=hi, n_batch=B, single_qp_solve=True,
                           max_linesearch_iter=5, linearised_residual=True)(*args)
     dev_u = np.abs(u.detach().cpu().numpy() - g["single_u"]).max()

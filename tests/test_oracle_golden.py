@@ -163,18 +163,10 @@ def _al_step(robot, dt):
             fx, fu = dyn_ref.jac_x(robot, x, u, dt)
             return dyn_ref.step_x(robot, x, u, dt), fx, fu
         return step
-    from test_dynamics_cpu import IDS, build_hostlib          # host build of the model templates (DYN_*.npz-pinned)
-    lib = build_hostlib()
-    if lib is None:
+    from oracle import dyn_host                     # host build of the model templates (DYN_*.npz-pinned)
+    step = dyn_host.stepper(robot, dt)
+    if step is None:
         pytest.skip("hipcc not available")
-
-    def step(x, u):
-        x, u = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(u, dtype=np.float64)
-        N, n, m = x.shape[0], x.shape[1], u.shape[1]
-        xn, Jx, Ju = np.empty((N, n)), np.empty((N, n, n)), np.empty((N, n, m))
-        assert lib.dyn_host_jac(IDS[robot], N, x.ctypes.data, u.ctypes.data, dt, xn.ctypes.data, Jx.ctypes.data,
-                                Ju.ctypes.data) == 0
-        return xn, Jx, Ju
     return step
 
 

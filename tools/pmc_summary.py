@@ -55,4 +55,6 @@ for f in glob.glob(os.path.join(out, "stats", "**", "*kernel_trace.csv"), recurs
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 res["_library_fingerprint"] = bench.library_fingerprint()
-print(json.dumps({k: v for k, v in res.items() if k == "_library_fingerprint" or "dqp" in k or "al_newton" in k or "al_chol" in k}, indent=1, sort_keys=True))
+# the library's own kernels only (torch / rocBLAS kernels of the policy network are not this package's)
+skip = ("at::", "Cijk_", "rocblas", "hipcub", "rocprim", "__amd", "elementwise", "vectorized", "reduce_kernel", "void at")
+print(json.dumps({k: v for k, v in res.items() if k == "_library_fingerprint" or not any(t in k for t in skip)}, indent=1, sort_keys=True))
