@@ -175,19 +175,31 @@ __device__ __forceinline__ void ls_step(const double *xs, const double *us, doub
     for (int k = 0; k < Map::NX; ++k) out[k] = o[k];
 }
 
-__device__ __forceinline__ double stage_cost(const LsP &P, long long b, int t, const double *xs, const double *us, int n, int m)
+// Stage cost in the reference's own order of operations (qp_wrapper.py:690-692:
+//   0.5 * ((xu[..., None] * C).sum(-2) * xu).sum(-1).sum(-1) + (xu * c).sum(-1).sum(-1)):
+// v_j = sum_i tau_i C_ij, quad_t = sum_j v_j tau_j, lin_t = sum_j tau_j c_j, every product rounded before it is added
+// (no FMA contraction: torch multiplies, then reduces), the quadratic and the linear part summed over the knots
+// separately and combined once (Cost::total).  The line search's accept test compares two costs that are equal up to
+// round-off at a converged SQP iterate: with the same association as the reference the tie falls the same way.
+struct Cost {
+    double quad = 0.0, lin = 0.0;
+    __device__ __forceinline__ double total() const { return __dadd_rn(__dmul_rn(0.5, quad), lin); }
+};
+__device__ __forceinline__ void stage_cost(const LsP &P, long long b, int t, const double *xs, const double *us, int n, int m, Cost &acc)
 {
     const int nt = n + m;
-    if (!P.C) return 0.0;                     // rollout only (dqp_mpc_line_search with C == NULL)
+    if (!P.C) return;                         // rollout only (dqp_mpc_line_search with C == NULL)
     const double *Ct = P.C + ((long long)t * P.B + b) * nt * nt, *ct = P.c + ((long long)t * P.B + b) * nt;
-    double acc = 0.0;
-    for (int i = 0; i < nt; ++i) {
-        const double ti = i < n ? xs[i] : us[i - n];
-        double row = 0.0;
-        for (int j = 0; j < nt; ++j) row += Ct[i * nt + j] * (j < n ? xs[j] : us[j - n]);
-        acc += ti * (0.5 * row + ct[i]);
+    double q = 0.0, l = 0.0;
+    for (int j = 0; j < nt; ++j) {
+        const double tj = j < n ? xs[j] : us[j - n];
+        double v = 0.0;
+        for (int i = 0; i < nt; ++i) v = __dadd_rn(v, __dmul_rn(i < n ? xs[i] : us[i - n], Ct[i * nt + j]));
+        q = __dadd_rn(q, __dmul_rn(v, tj));
+        l = __dadd_rn(l, __dmul_rn(tj, ct[j]));
     }
-    return acc;
+    acc.quad = __dadd_rn(acc.quad, q);
+    acc.lin = __dadd_rn(acc.lin, l);
 }
 
 // One instantiation per dynamics (the LinDx form with run-time sizes, one per registered model with its
@@ -199,22 +211,24 @@ template <int N, int M_> struct LinStepT { static constexpr bool LIN = true, FIX
 template <class Map> struct ModelStep { static constexpr bool LIN = false, FIXED = true; static constexpr int NX = Map::NX, NU = Map::NU; using M = Map; };
 #define DQP_LIN_SIZES X(3, 3) X(3, 1) X(4, 1) X(6, 1) X(2, 1) X(4, 2) X(3, 2) X(12, 4)
 
-// 0.5 tau' C tau + c' tau with the knot's C_t, c_t in registers (same summation order as stage_cost)
+// the same with the knot's C_t, c_t in registers (same order of operations as stage_cost)
 template <int NX, int NU>
-__device__ __forceinline__ double stage_cost_regs(const double (&Ct)[(NX + NU) * (NX + NU)], const double (&ct)[NX + NU],
-                                                  const double (&xs)[NX], const double (&us)[NU])
+__device__ __forceinline__ void stage_cost_regs(const double (&Ct)[(NX + NU) * (NX + NU)], const double (&ct)[NX + NU],
+                                                const double (&xs)[NX], const double (&us)[NU], Cost &acc)
 {
     constexpr int NT = NX + NU;
-    double acc = 0.0;
+    double q = 0.0, l = 0.0;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const double ti = i < NX ? xs[i < NX ? i : 0] : us[i >= NX ? i - NX : 0];
-        double row = 0.0;
+    for (int j = 0; j < NT; ++j) {
+        const double tj = j < NX ? xs[j < NX ? j : 0] : us[j >= NX ? j - NX : 0];
+        double v = 0.0;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) row += Ct[i * NT + j] * (j < NX ? xs[j < NX ? j : 0] : us[j >= NX ? j - NX : 0]);
-        acc += ti * (0.5 * row + ct[i]);
+        for (int i = 0; i < NT; ++i) v = __dadd_rn(v, __dmul_rn(i < NX ? xs[i < NX ? i : 0] : us[i >= NX ? i - NX : 0], Ct[i * NT + j]));
+        q = __dadd_rn(q, __dmul_rn(v, tj));
+        l = __dadd_rn(l, __dmul_rn(tj, ct[j]));
     }
-    return acc;
+    acc.quad = __dadd_rn(acc.quad, q);
+    acc.lin = __dadd_rn(acc.lin, l);
 }
 
 // Registered models with small knots: the thread is a chain of T knots "load C_t, c_t, u_t, du_t -> cost ->
@@ -245,11 +259,12 @@ __device__ __forceinline__ void line_search_model(const LsP &P, long long b)
         }
     };
     double alpha = 1.0, cost_try = 0.0, cost_here = 0.0;
+    Cost here;
     for (int round = 0; round < P.max_iter; ++round) {
         double xs[NX], us[NU], nx[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) xs[i] = px0[b * NX + i];
-        cost_try = 0.0;
+        Cost tr;
         load(0, round == 0);
         for (int t = 0; t < T; ++t) {
             const long long k = (long long)t * B + b;
@@ -257,14 +272,16 @@ __device__ __forceinline__ void line_search_model(const LsP &P, long long b)
             for (int i = 0; i < NU; ++i) { us[i] = pdu ? u0[i] + du[i] * alpha : u0[i]; pun[k * NU + i] = us[i]; }
 #pragma unroll
             for (int i = 0; i < NX; ++i) pxn[k * NX + i] = xs[i];
-            if (round == 0) cost_here += stage_cost_regs<NX, NU>(Ct, ct, xc, u0);
-            cost_try += stage_cost_regs<NX, NU>(Ct, ct, xs, us);
+            if (round == 0) stage_cost_regs<NX, NU>(Ct, ct, xc, u0, here);
+            stage_cost_regs<NX, NU>(Ct, ct, xs, us, tr);
             if (t == T - 1) break;
             load(t + 1, round == 0);
             ls_step<typename S::M>(xs, us, P.dt, nx);
 #pragma unroll
             for (int i = 0; i < NX; ++i) xs[i] = nx[i];
         }
+        cost_try = tr.total();
+        if (round == 0) cost_here = here.total();
         if (cost_try < cost_here) break;            // improved: this alpha stands
         alpha *= P.decay;                           // qp_wrapper.py:431-432
     }
@@ -281,18 +298,19 @@ __global__ __launch_bounds__(64) void line_search_kernel(LsP P)
         if (P.C) { line_search_model<S>(P, b); return; }
     }
     const int n = S::FIXED ? S::NX : P.n, m = S::FIXED ? S::NU : P.m, T = P.T, nt = n + m;
-    double cost_here = 0.0;
+    Cost here;
     for (int t = 0; t < T && P.C; ++t) {
         double xs[S::NX], us[S::NU];
         for (int i = 0; i < n; ++i) xs[i] = P.x[((long long)t * P.B + b) * n + i];
         for (int i = 0; i < m; ++i) us[i] = P.u[((long long)t * P.B + b) * m + i];
-        cost_here += stage_cost(P, b, t, xs, us, n, m);
+        stage_cost(P, b, t, xs, us, n, m, here);
     }
+    const double cost_here = here.total();
     double alpha = 1.0, cost_try = 0.0;
     for (int round = 0; round < P.max_iter; ++round) {
         double xs[S::NX], us[S::NU], nx[S::NX];
         for (int i = 0; i < n; ++i) xs[i] = P.x0[b * n + i];
-        cost_try = 0.0;
+        Cost tr;
         for (int t = 0; t < T; ++t) {
             for (int i = 0; i < m; ++i) {
                 const long long o = ((long long)t * P.B + b) * m + i;
@@ -300,7 +318,7 @@ __global__ __launch_bounds__(64) void line_search_kernel(LsP P)
                 P.un[o] = us[i];
             }
             for (int i = 0; i < n; ++i) P.xn[((long long)t * P.B + b) * n + i] = xs[i];
-            cost_try += stage_cost(P, b, t, xs, us, n, m);
+            stage_cost(P, b, t, xs, us, n, m, tr);
             if (t == T - 1) break;
             if constexpr (S::LIN) {     // LinDx: x+ = F_t [x; u] + f_t
                 const double *Ft = P.F + ((long long)t * P.B + b) * n * nt, *ft = P.f + ((long long)t * P.B + b) * n;
@@ -314,6 +332,7 @@ __global__ __launch_bounds__(64) void line_search_kernel(LsP P)
             }
             for (int i = 0; i < n; ++i) xs[i] = nx[i];
         }
+        cost_try = tr.total();
         if (cost_try < cost_here) break;            // improved: this alpha stands
         alpha *= P.decay;                           // qp_wrapper.py:431-432
     }

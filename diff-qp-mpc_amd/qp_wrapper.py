@@ -667,8 +667,10 @@ class MPC(Module):
     # ------------------------------------------------------------------ behaviour of qp_wrapper.py:690-692
     def compute_cost(self, xu, cost):
         """Total quadratic cost of batch-major trajectories xu (B,T,n+m) under time-major (C, c)."""
-        Cx = torch.matmul(cost.C.transpose(0, 1), xu[..., None])[..., 0]          # (B,T,n+m)
-        return (xu * (0.5 * Cx + cost.c.transpose(0, 1))).sum(dim=(1, 2))
+        C, c = cost.C.transpose(0, 1), cost.c.transpose(0, 1)
+        # the reference's order of operations (qp_wrapper.py:690-692): the line search compares costs that are equal up
+        # to round-off at a converged iterate
+        return 0.5 * ((xu.unsqueeze(-1) * C).sum(dim=-2) * xu).sum(dim=-1).sum(dim=-1) + (xu * c).sum(dim=-1).sum(dim=-1)
 
 
 class _GraphReplay(Function):

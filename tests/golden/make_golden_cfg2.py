@@ -66,8 +66,18 @@ for tag, kw in (("single", dict(single_qp_solve=True)), ("sqp3", dict(qp_iter=3)
     ctrl = qp_wrapper.MPC(n, mm, T, u_lower=torch.tensor([dx.lower]), u_upper=torch.tensor([dx.upper]),
                           n_batch=B, max_linesearch_iter=dx.max_linesearch_iter,
                           linesearch_decay=dx.linesearch_decay, **kw)
+    # the step factor of the LAST line search (the differentiable step is scaled by it, qp_wrapper.py:405-413): at a
+    # converged iterate it is decided by round-off of the cost comparison, so it is recorded next to the gradients
+    alphas = []
+    ls = ctrl.line_search
+    def recording_line_search(*a, **k):
+        r = ls(*a, **k)
+        alphas.append(r[2].detach().reshape(-1).numpy().copy())
+        return r
+    ctrl.line_search = recording_line_search
     x, u = ctrl(x0, qp_wrapper.QuadCost(C, c), dx, dx_jac)
     (x.sum() + 2.0 * u.sum()).backward()
+    out[tag + "_alpha"] = alphas[-1]
     out[tag + "_x"], out[tag + "_u"] = x.detach().numpy(), u.detach().numpy()
     out[tag + "_dC"], out[tag + "_dc"] = C.grad.numpy(), c.grad.numpy()
     # dynamics consistency of the reference's own answer (line search rolls the true model out)

@@ -3,8 +3,9 @@ C ABI, against (1) the golden vectors captured from the reference and (2) the CP
 seeded inputs, plus size-independent KKT properties at the full benchmark size.
 
 Tolerances (fp64), stated per SURVEY.md §8c: the reference's own two solvers agree to 3e-13 on
-zhat and 5e-6 on gradients; termination here is per problem instead of batch-coupled, so
-parity is a float tolerance, never iteration-exact:
+zhat and 5e-6 on gradients.  The default termination is the reference's batch-coupled rule replayed
+on the device (every test also runs the opt-in per-problem mode where it says so); the kernels work
+in different coordinates than the reference, so parity is a float tolerance, never bit-exact:
     zhat            rtol 1e-6  atol 1e-8
     lam, nu, slack  rtol 1e-5  atol 1e-7
     gradients       rtol 1e-4  atol 1e-6
@@ -17,7 +18,7 @@ import pytest
 import torch
 
 from oracle import oracle
-from families import family, family_mpc, broke_down
+from families import family, family_mpc
 
 pytestmark = pytest.mark.gpu
 
@@ -65,18 +66,41 @@ def family_R(seed, B, nz, nineq, neq):
     return family(seed, B, nz, nineq, neq, "R")
 
 
-def reference_outputs(ins):
-    """Oracle forward for a stress batch: the strict restatement of batch.py, except on samples
-    where the reference's unguarded get_step divided by an exactly-zero step component and froze
-    the iterate (families.broke_down) -- those are taken from the guarded variant (the reference's
-    own batch_LU.get_step), both pinned by tests/golden (test_oracle_golden.py)."""
-    o = oracle.qp_forward(*ins)
-    bd = broke_down(o["resid_hist"], o["iters"])
-    if bd.any():
-        o2 = oracle.qp_forward(*ins, guard=True)
-        for k in ("zhat", "lam", "nu", "slack", "best_resid"):
-            o[k][bd] = o2[k][bd]
-    return o, bd
+def over_tolerance(a, b):
+    """per-sample: do the forward outputs of two runs differ beyond the test tolerances (NaN counts as differing)?"""
+    bad = np.zeros(a["zhat"].shape[0], dtype=bool)
+    for k, tol in (("zhat", ZT), ("lam", DT), ("nu", DT), ("slack", DT)):
+        e = np.abs(a[k] - b[k]) > tol["atol"] + tol["rtol"] * np.abs(b[k])
+        bad |= (e | np.isnan(a[k]) | np.isnan(b[k])).reshape(e.shape[0], -1).any(1)
+    return bad
+
+
+def reference_outputs(ins, ct=None):
+    """Oracle forward (and, with a cotangent, backward) for a stress batch -> (outputs, differ[, gradients]).
+    Expected = the LITERAL restatement of batch.py (unguarded get_step, batch.py:211-214) on every sample, except
+    those where the literal run and the guarded run (the reference's own batch_LU.get_step, batch_LU.py:203-214)
+    actually DIFFER beyond the test tolerances, in an output or in a gradient: there the literal reference froze its
+    iterate on a division by an exactly-zero step component one or two iterations short of convergence (which moves
+    d = lam/slack of weakly active constraints, hence the gradients) -- an accident of its arithmetic order that
+    kernels working in other coordinates do not share -- and the guarded run is the expectation.  Samples whose
+    literal history turns NaN only after convergence (most of them: the two runs then agree) stay with the literal
+    oracle.  Both variants are pinned by tests/golden (test_oracle_golden.py).  Counts over 8192 samples per family:
+    tools/strict_vs_guard.py, profiles/r3/strict_vs_guard.log."""
+    lit = oracle.qp_forward(*ins)
+    grd = oracle.qp_forward(*ins, guard=True)
+    differ = over_tolerance(lit, grd)
+    gl = gg = None
+    if ct is not None:
+        gl = oracle.qp_backward(ins[0], ins[2], ins[4], lit["zhat"], lit["lam"], lit["nu"], lit["slack"], ct)
+        gg = oracle.qp_backward(ins[0], ins[2], ins[4], grd["zhat"], grd["lam"], grd["nu"], grd["slack"], ct)
+        for k in gl:
+            e = ~(np.abs(gl[k] - gg[k]) <= GT["atol"] + GT["rtol"] * np.abs(gg[k]))
+            differ |= e.reshape(e.shape[0], -1).any(1)
+        for k in gl:
+            gl[k][differ] = gg[k][differ]
+    for k in ("zhat", "lam", "nu", "slack", "best_resid"):
+        lit[k][differ] = grd[k][differ]
+    return (lit, differ) if ct is None else (lit, differ, gl)
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -161,9 +185,11 @@ def test_stress_families_metric_shape(dqp, kind, seed):
     d = lam/slack of weakly active constraints (parity section)."""
     B, nz, nineq, neq = 2048, 30, 30, 15
     ins_np = family_mpc(seed, B) if kind == "M" else family(1000 * seed + nz, B, nz, nineq, neq, kind)
-    o, bd = reference_outputs(ins_np)
-    if kind == "M":
-        assert bd.sum() > 0
+    ct = np.random.default_rng(seed).standard_normal((B, nz))
+    o, differ, og = reference_outputs(ins_np, ct)
+    # literal parity on all but the samples where the reference's two step rules part ways (printed with -s)
+    print("literal and guarded reference differ on", np.nonzero(differ)[0])
+    assert differ.sum() <= 2, np.nonzero(differ)[0]       # M seed 0: #174 #1889; M seed 1: #1206; D seed 1: #1782; D seed 3: none
     cm = o["best_resid"] < 1e-8
     assert cm.mean() > 0.99
     from diff_qp_mpc_amd import qp as qpmod
@@ -174,12 +200,13 @@ def test_stress_families_metric_shape(dqp, kind, seed):
     np.testing.assert_allclose(lam.cpu().numpy()[cm], o["lam"][cm], **DT)
     np.testing.assert_allclose(nu.cpu().numpy()[cm], o["nu"][cm], **DT)
     np.testing.assert_allclose(slack.cpu().numpy()[cm], o["slack"][cm], **DT)
-    ct = np.random.default_rng(seed).standard_normal((B, nz))
     gr = qpmod._backward_impl(saved, zhat, lam, nu, slack, dev(ct, grad=False), (True,) * 6,
                               qpmod.FORCE_FLAGS)
-    og = oracle.qp_backward(ins_np[0], ins_np[2], ins_np[4], o["zhat"], o["lam"], o["nu"], o["slack"], ct)
-    gm = cm & (np.maximum(o["lam"], o["slack"]).min(1) > 1e-5)       # strict complementarity
-    assert gm.mean() > 0.9
+    # gradients are compared where strict complementarity holds (min_i max(lam_i, slack_i) > 1e-5: elsewhere
+    # d = lam/slack swings by O(1) on 1e-10 changes of the iterate); that drops at most 2 of the 2048 problems
+    # of these batches (1, 0, 2, 0 in the order of the parametrisation)
+    gm = cm & (np.maximum(o["lam"], o["slack"]).min(1) > 1e-5)
+    assert (~gm).sum() <= 2, (~gm).sum()
     for k, t in zip("QpGhAb", gr):
         np.testing.assert_allclose(t.cpu().numpy()[gm], og["d" + k][gm], err_msg="d" + k, **GT)
 
@@ -392,3 +419,40 @@ def test_global_batch_rule_over_shards(dqp, kind):
         got = torch.cat([o[k] for o in outs], 0)
         assert torch.equal(got, whole[k]), "output %d differs from the single-batch solve" % k
     assert torch.equal(torch.cat([o[4] for o in outs], 0)[:, 1], whole[4][:, 1])        # iterations
+
+
+def test_strict_get_step_flag_freezes_on_exact_zero(dqp):
+    """DQP_FLAG_STRICT_GET_STEP (batch.py:211-214 literally: a step component that is exactly 0.0 freezes the problem
+    at the best iterate it had).  Which problems meet an exact zero depends on the arithmetic order, so the flag is
+    pinned through what it must and must not do on the MPC-structured family (box rows whose multiplier step cancels
+    to 0.0 do occur in the kernels' arithmetic too), in the per-problem mode where problems do not influence each
+    other: a problem that never meets one is untouched bit for bit; a frozen problem ran fewer iterations and its best
+    residual is no better than the default's; the flag fires on a minority of the problems; and under the batch rule
+    the forward outputs stay within the test tolerances of the literal oracle wherever the literal and the guarded
+    oracle agree (the gradients of a frozen problem move with its weakly active d = lam/slack, as the reference's do:
+    tools/strict_vs_guard.py)."""
+    from diff_qp_mpc_amd import qp as qpmod, _lib
+    B = 2048
+    ins_np = family_mpc(0, B)
+    dv = [dev(a, grad=False) for a in ins_np]
+    base = qpmod.FORCE_FLAGS
+
+    def run(flag, termination):
+        qpmod.FORCE_FLAGS = base | flag
+        try:
+            return qpmod._forward_impl(*dv, 1e-12, 20, 3, termination=termination)
+        finally:
+            qpmod.FORCE_FLAGS = base
+    z0, l0, n0, s0, i0, r0, _ = run(0, "per_problem")
+    z1, l1, n1, s1, i1, r1, _ = run(_lib.DQP_FLAG_STRICT_GET_STEP, "per_problem")
+    it0, it1 = i0[:, 1].cpu().numpy(), i1[:, 1].cpu().numpy()
+    same = ((z0 == z1).all(1) & (l0 == l1).all(1) & (s0 == s1).all(1)).cpu().numpy()
+    assert (it1 <= it0).all()
+    frozen = it1 < it0
+    assert same[~frozen].all()                                   # untouched unless frozen
+    assert (r1.cpu().numpy()[frozen] >= r0.cpu().numpy()[frozen]).all()
+    assert 1 <= frozen.sum() < B // 2, frozen.sum()
+    z2, l2, n2, s2, _, _, _ = run(_lib.DQP_FLAG_STRICT_GET_STEP, "batch")
+    o, differ = reference_outputs(ins_np)
+    got = {"zhat": z2.cpu().numpy(), "lam": l2.cpu().numpy(), "nu": n2.cpu().numpy(), "slack": s2.cpu().numpy()}
+    assert not over_tolerance(got, o)[~differ].any()

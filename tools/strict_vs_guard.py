@@ -5,8 +5,9 @@
 Per family (R: random dense, D: diagonal cost, M: MPC-structured; metric shape 30/30/15), SEEDS batches of BATCH:
   * `nan`      samples whose residual history turns NaN in the literal oracle while the batch iterates (a zero step
                component was met: the iterate is frozen);
-  * `differ`   samples where literal and guarded oracle outputs (zhat, lam, nu, slack) differ beyond the test
-               tolerances -- the only samples on which "which reference?" matters;
+  * `differ`   samples where literal and guarded oracle outputs (zhat, lam, nu, slack) or gradients (all six, random
+               cotangent, where strict complementarity holds) differ beyond the test tolerances -- the only samples on
+               which "which reference?" matters;
   * GPU default (guarded): worst deviation / tolerance against the LITERAL oracle on the non-differing samples, and
                against the guarded oracle on the differing ones; number of samples over tolerance against the literal one;
   * GPU DQP_FLAG_STRICT_GET_STEP: samples over tolerance against the literal oracle (the flag freezes a problem on an exact
@@ -38,15 +39,29 @@ def over(x, ref):
     return w
 
 
-def gpu(ins, flags):
+GT = (1e-4, 1e-6)
+
+
+def grad_over(a, b):
+    w = np.zeros(a["dQ"].shape[0])
+    for k in a:
+        e = np.abs(a[k] - b[k]) / (GT[1] + GT[0] * np.abs(b[k]))
+        e = np.where(np.isnan(e), np.inf, e)
+        w = np.maximum(w, e.reshape(e.shape[0], -1).max(1))
+    return w
+
+
+def gpu(ins, flags, ct):
     dv = [torch.tensor(a, device="cuda") for a in ins]
     qpmod.FORCE_FLAGS = flags
     try:
-        zhat, lam, nu, slack, info, resid, _ = qpmod._forward_impl(*dv, 1e-12, 20, 3)
+        zhat, lam, nu, slack, info, resid, saved = qpmod._forward_impl(*dv, 1e-12, 20, 3)
+        gr = qpmod._backward_impl(saved, zhat, lam, nu, slack, torch.tensor(ct, device="cuda"), (True,) * 6, flags)
     finally:
         qpmod.FORCE_FLAGS = 0
     torch.cuda.synchronize()
-    return {"zhat": zhat.cpu().numpy(), "lam": lam.cpu().numpy(), "nu": nu.cpu().numpy(), "slack": slack.cpu().numpy()}
+    out = {"zhat": zhat.cpu().numpy(), "lam": lam.cpu().numpy(), "nu": nu.cpu().numpy(), "slack": slack.cpu().numpy()}
+    return out, {"d" + k: t.cpu().numpy() for k, t in zip("QpGhAb", gr)}
 
 
 def main():
@@ -63,11 +78,17 @@ def main():
             grd = oracle.qp_forward(*ins, guard=True)
             conv = grd["best_resid"] < 1e-8                 # as the tests: problems the oracle itself converged on
             nanm = broke_down(lit["resid_hist"], lit["iters"])
-            differ = (over(lit, grd) > 1.0) & conv
+            ct = np.random.default_rng(seed).standard_normal((B, nz))
+            bw = lambda o: oracle.qp_backward(ins[0], ins[2], ins[4], o["zhat"], o["lam"], o["nu"], o["slack"], ct)
+            g_lit, g_grd = bw(lit), bw(grd)
+            sc = np.maximum(grd["lam"], grd["slack"]).min(1) > 1e-5           # strict complementarity (gradients defined)
+            differ = ((over(lit, grd) > 1.0) | ((grad_over(g_lit, g_grd) > 1.0) & sc)) & conv
             agree = ~differ & conv
-            g0 = gpu(ins, 0)
-            gs = gpu(ins, _lib.DQP_FLAG_STRICT_GET_STEP)
-            o_lit, o_grd, s_lit = over(g0, lit), over(g0, grd), over(gs, lit)
+            g0, gg0 = gpu(ins, 0, ct)
+            gs, ggs = gpu(ins, _lib.DQP_FLAG_STRICT_GET_STEP, ct)
+            o_lit = np.maximum(over(g0, lit), np.where(sc, grad_over(gg0, g_lit), 0.0))
+            o_grd = np.maximum(over(g0, grd), np.where(sc, grad_over(gg0, g_grd), 0.0))
+            s_lit = np.maximum(over(gs, lit), np.where(sc, grad_over(ggs, g_lit), 0.0))
             acc["samples"] += B; acc["conv"] += int(conv.sum()); acc["nan"] += int(nanm.sum()); acc["differ"] += int(differ.sum())
             acc["gpu_over_literal_on_agree"] += int((o_lit[agree] > 1.0).sum())
             acc["gpu_worst_literal_on_agree"] = max(acc["gpu_worst_literal_on_agree"], float(o_lit[agree].max(initial=0.0)))
