@@ -336,6 +336,9 @@ def line_search_newton(update, x_est, meritfnQ, merit, x0):
     return keep * x_new + (1 - keep) * x_est, best, steps[idx, ar].mean(), status
 
 
+DENSE_NEWTON_MAX_NZ = 128      # dqp_al_newton_step (csrc/dqp_al.hip): the Hessian of one problem in the LDS of a CU
+
+
 class NewtonAL(torch.autograd.Function):
     """Four Newton steps on the augmented Lagrangian + implicit backward (al_utils.py:363-500)."""
 
@@ -345,7 +348,9 @@ class NewtonAL(torch.autograd.Function):
         B, T, nt = xi.shape
         x_est = xi
         merit = meritfn(x_est, Q, q, lam, x0, rho)
-        chol_failed = False
+        # beyond the dense Newton kernel's size (dqp_al_newton_step: nz <= 128) this general path is only reached as
+        # the reference's LU fallback of a failed block-tridiagonal factorisation (AL_mpc.al_solve): solve by LU
+        chol_failed = T * nt > DENSE_NEWTON_MAX_NZ
         status = None
         terms = L = None
         for _ in range(MAX_NEWTON_STEPS):          # merit_delta is pinned to 1000 (al_utils.py:453)

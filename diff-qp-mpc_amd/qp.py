@@ -11,7 +11,8 @@ Differences from the reference, all documented in DESIGN.md:
   * termination: the reference's batch-coupled rule (batch.py:119-144) is reproduced on the
     device by default (TERMINATION = "batch"); "per_problem" lets every problem stop on its own
     (include/dqp.h) -- faster in very large batches, float-tolerance parity.
-  * `check_Q_spd` uses the kernel's Cholesky status instead of B host-side eig calls.
+  * `check_Q_spd` uses the kernel's Cholesky status instead of B host-side eig calls, and -- like the INACC_ERR
+    warning -- reaches the host lazily (CHECKS below): no device synchronisation inside forward.
   * solver=QPSolvers.CVXPY is not available (cvxpy is an offline oracle in the reference).
 """
 import ctypes
@@ -44,6 +45,47 @@ MASK_EXCHANGE = None
 # extra dqp_opts.flags OR-ed into every call (tests use DQP_FLAG_GENERIC_ONLY / _NO_NULLSPACE to
 # pin a kernel family; 0 = automatic dispatch)
 FORCE_FLAGS = 0
+
+
+# How QPFunction's result checks reach the host (`check_Q_spd` -> RuntimeError('Q is not SPD.'), qp.py:86; the INACC_ERR
+# warning for verbose >= 0, batch.py:142-143).  The reference runs them inside forward, which costs a device
+# synchronisation per solve.  "lazy" (default): forward only enqueues a two-flag reduction and its copy to pinned host
+# memory; the flags are looked at -- and the error raised / the warning printed -- at the first of: the backward of that
+# call, the next forward of any QPFunction (once the copy has landed), or flush_checks().  "sync": as the reference.
+CHECKS = "lazy"
+_pending = []
+
+
+def _enqueue_checks(info, resid, want_spd, want_inacc):
+    flags = torch.stack(((info[:, 0] == _lib.DQP_STATUS_Q_NOT_PD).any(), resid.max() > 1.0))
+    host = torch.empty(2, dtype=torch.bool, pin_memory=True)
+    host.copy_(flags, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(info.device))
+    entry = [ev, host, want_spd, want_inacc]
+    _pending.append(entry)
+    return entry
+
+
+def _resolve(entry, wait):
+    """Look at one pending check (waiting for its copy if asked to); returns False while it is still in flight."""
+    ev, host, want_spd, want_inacc = entry
+    if not wait and not ev.query():
+        return False
+    ev.synchronize()
+    if entry in _pending:
+        _pending.remove(entry)
+    if want_inacc and bool(host[1]):
+        print(INACC_ERR)                                             # batch.py:142-143
+    if want_spd and bool(host[0]):
+        raise RuntimeError('Q is not SPD.')                          # qp.py:86
+    return True
+
+
+def flush_checks(wait=True):
+    """Resolve the lazy result checks of earlier forward calls (raises / prints as the reference's forward would have)."""
+    for entry in list(_pending):
+        _resolve(entry, wait)
 
 
 class QPSolvers(Enum):
@@ -215,13 +257,12 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3, maxIter=20,
                 _check_callables(Q_, p_, A_, b_, closure, cost_grad, nBatch)
             zhat, lam, nu, slack, info, resid, saved = _forward_impl(
                 Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim, dyn=dyn)
-            if check_Q_spd:
-                st = info[:, 0]
-                if bool((st == _lib.DQP_STATUS_Q_NOT_PD).any()):
-                    raise RuntimeError('Q is not SPD.')              # qp.py:86
-            if verbose >= 0:
-                if bool((resid.max() > 1.0)):                        # batch.py:142-143
-                    print(INACC_ERR)
+            ctx.check = None
+            if check_Q_spd or verbose >= 0:
+                flush_checks(wait=False)                             # earlier calls whose flags have landed
+                ctx.check = _enqueue_checks(info, resid, check_Q_spd, verbose >= 0)
+                if CHECKS == "sync":
+                    _resolve(ctx.check, True)
             ctx.saved = saved
             ctx.lams, ctx.nus, ctx.slacks, ctx.info = lam, nu, slack, info
             ctx.shared = tuple(t.numel() > 0 and t.dim() == nd - 1 for t, nd in
@@ -234,6 +275,8 @@ def QPFunction(eps=1e-12, verbose=0, notImprovedLim=3, maxIter=20,
         @staticmethod
         def backward(ctx, dl_dzhat):
             zhat, = ctx.saved_tensors
+            if ctx.check is not None and ctx.check in _pending:
+                _resolve(ctx.check, True)
             need = ctx.needs_input_grad[:6]
             grads = list(_backward_impl(ctx.saved, zhat, ctx.lams, ctx.nus, ctx.slacks,
                                         dl_dzhat, need, 0))

@@ -48,12 +48,14 @@ def merit(xu, Qd, q, x0, lam, rho, u_lower, u_upper, step):
 
 def newton_al(xu, x0, lam, rho, Qd, q, u_lower, u_upper, step):
     """NewtonAL.forward: four Newton steps on the augmented Lagrangian, each followed by the 20-candidate line
-    search.  -> (x_est, L of the last step, status)."""
+    search.  -> (x_est, L of the last step -- or its Hessian H once a Cholesky factorisation failed --, status,
+    chol_fail)."""
     B, T, nt = xu.shape
     n = x0.shape[1]
     x_est = xu.copy()
     mer = merit(x_est, Qd, q, x0, lam, rho, u_lower, u_upper, step)
-    L = status = None
+    L = status = H = None
+    chol_fail = False
     for _ in range(NEWTON_STEPS):
         res, resc, J, Jc = al_oracle.constraint_jacobian(x_est, x0, u_lower, u_upper, step)
         grad = ((Qd * x_est + q).reshape(B, -1) + np.matmul(lam[:, None, :], J)[:, 0]
@@ -61,9 +63,16 @@ def newton_al(xu, x0, lam, rho, Qd, q, u_lower, u_upper, step):
         H = np.matmul(Jc.transpose(0, 2, 1), Jc) * rho[:, :, None]
         idx = np.arange(T * nt)
         H[:, idx, idx] += Qd.reshape(B, -1)
-        L = np.linalg.cholesky(H)
-        y = np.linalg.solve(L, -grad[:, :, None])
-        update = np.linalg.solve(L.transpose(0, 2, 1), y)[:, :, 0].reshape(B, T, nt)
+        if not chol_fail:
+            try:
+                L = np.linalg.cholesky(H)
+                y = np.linalg.solve(L, -grad[:, :, None])
+                update = np.linalg.solve(L.transpose(0, 2, 1), y)[:, :, 0].reshape(B, T, nt)
+            except np.linalg.LinAlgError:
+                chol_fail = True        # al_utils.py:419-427: NaN update -> LU for the whole batch, this step and after
+        if chol_fail:
+            L = None
+            update = np.linalg.solve(H, -grad[:, :, None])[:, :, 0].reshape(B, T, nt)
         # line_search_newton: candidates x + 2^-k update, the first knot's state pinned to x0
         best = np.full(B, np.inf)
         x_best = x_est.copy()
@@ -77,7 +86,7 @@ def newton_al(xu, x0, lam, rho, Qd, q, u_lower, u_upper, step):
         status = best < mer
         x_est = np.where(status[:, None, None], x_best, x_est)
         mer = best                      # `merit = new_merit` whether or not the step was accepted
-    return x_est, L, status
+    return x_est, (H if chol_fail else L), status, chol_fail
 
 
 def warm_start(lam, cost_start, cost_hist, lam_hist, rho_hist):
@@ -102,21 +111,25 @@ def al_solve(x, u, x0, Qd, q, u_lower, u_upper, step, lam, rho, al_iter=2, histo
         lam, rho = warm_start(lam, cost_start, ch, lh, rh)
     hist = [[cost_start], [lam], [rho]]
     neq = T * n
-    L = None
+    L, chol_fail = None, False
     for _ in range(al_iter):
-        xu, L, _ = newton_al(xu, x0, lam, rho, Qd, q, u_lower, u_upper, step)
+        xu, L, _, chol_fail = newton_al(xu, x0, lam, rho, Qd, q, u_lower, u_upper, step)
         res, _ = residuals(xu, x0, u_lower, u_upper, step)
         lam = lam + rho * res
         lam = np.concatenate((lam[:, :neq], np.maximum(lam[:, neq:], 0.0)), 1)
         rho = rho * 10.0
         hist[0].append(compute_cost(xu, Qd, q)); hist[1].append(lam); hist[2].append(rho)
-    return dict(x=xu[:, :, :n], u=xu[:, :, n:], xu=xu, lam=lam, rho=rho, L=L, history=hist)
+    return dict(x=xu[:, :, :n], u=xu[:, :, n:], xu=xu, lam=lam, rho=rho, L=L, chol_fail=chol_fail, history=hist)
 
 
-def backward(L, xu, grad_xu):
-    """NewtonAL.backward: inp_grad = -H^-1 g through the last Cholesky factor; dQ = inp_grad * x, dq = inp_grad."""
+def backward(L, xu, grad_xu, chol_fail=False):
+    """NewtonAL.backward: inp_grad = -H^-1 g through the last Cholesky factor (or, after a Cholesky failure, an LU
+    solve with the last Hessian, passed as L); dQ = inp_grad * x, dq = inp_grad."""
     B = xu.shape[0]
     g = grad_xu.reshape(B, -1, 1)
-    y = np.linalg.solve(L, g)
-    inp = -np.linalg.solve(L.transpose(0, 2, 1), y)[:, :, 0].reshape(xu.shape)
+    if chol_fail:
+        inp = -np.linalg.solve(L, g)[:, :, 0].reshape(xu.shape)
+    else:
+        y = np.linalg.solve(L, g)
+        inp = -np.linalg.solve(L.transpose(0, 2, 1), y)[:, :, 0].reshape(xu.shape)
     return inp * xu, inp

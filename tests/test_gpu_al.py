@@ -518,3 +518,47 @@ def test_al_mpc_user_dynamics_module_banded(name, robot, group, monkeypatch):
         np.testing.assert_allclose(u2.cpu().numpy(), g["u2"], rtol=1e-4, atol=1e-4)
     finally:
         AL_mpc.BANDED_USER_DYNAMICS_FROM_NZ = old
+
+
+@pytest.mark.parametrize("name,robot", [("CFG5_cartpole2l_T5_b4", "cartpole2l"), ("CFG4_rexquadrotor_T30_b4", "rexquadrotor")])
+def test_al_mpc_cholesky_failure_takes_the_lu_path(name, robot):
+    """A merit Hessian that is not positive definite (one sample's control cost made strongly negative): the
+    reference's NewtonAL sees a NaN Cholesky update and switches the batch to an LU solve, this step and after
+    (al_utils.py:419-427), backward included (:468-472).  AL_mpc.MPC on the device path notices the failure flag,
+    redoes the solve on the general path -- dense Newton kernel below nz = 128 (cartpole-2: nz 35), straight LU above
+    it (quadrotor T = 30: nz 480, beyond dqp_al_newton_step) -- and must agree with the numpy oracle of the whole
+    call (oracle/al_solve_oracle.py, pinned by the same fixtures): x, u rtol 1e-4 / atol 1e-4, gradients of the
+    healthy samples rtol 1e-3 / atol 1e-5 (an indefinite Newton system is badly conditioned)."""
+    from diff_qp_mpc_amd import AL_mpc, al_utils
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    from oracle import al_solve_oracle as aso, dyn_host
+    g = load(name)
+    B, T = g["in_Qd"].shape[:2]
+    dyn = DeviceDynamics(robot, dt=float(g["dt"]))
+    nx, nu = dyn.n_state, dyn.n_ctrl
+    Qd = g["in_Qd"].copy()
+    Qd[1, :, nx:] = -5.0e3                                  # sample 1: negative control cost -> indefinite Hessian
+    step = dyn_host.stepper(robot, float(g["dt"]))
+    if step is None:
+        pytest.skip("hipcc not available for the host build of the dynamics")
+    lam0, rho0 = np.zeros((B, T * nx + 2 * T * nu)), np.ones((B, 1))
+    o = aso.al_solve(g["in_x_init"], g["in_u_init"], g["in_x0"], Qd, g["in_c"], g["in_u_lower"], g["in_u_upper"], step,
+                     lam0, rho0)
+    assert o["chol_fail"]
+    x0 = dev(g["in_x0"])
+    C = torch.diag_embed(dev(Qd)).requires_grad_()
+    c = dev(g["in_c"], grad=True)
+    ctrl = AL_mpc.MPC(nx, nu, T, u_lower=dev(g["in_u_lower"]), u_upper=dev(g["in_u_upper"]), n_batch=B, verbose=0,
+                      solver_type="dense", dtype=torch.float64, eps=1e-5, exit_unconverged=False, backprop=False)
+    ctrl.reinitialize(x0, torch.ones(B, T, 1, device="cuda"))
+    ctrl.x_init, ctrl.u_init = dev(g["in_x_init"]), dev(g["in_u_init"])
+    x, u = ctrl(x0, al_utils.QuadCost(C, c), dyn, dyn.jac)
+    ok = np.array([0, 2, 3])
+    np.testing.assert_allclose(x.detach().cpu().numpy()[ok], o["x"][ok], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(u.detach().cpu().numpy()[ok], o["u"][ok], rtol=1e-4, atol=1e-4)
+    assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(u).all())
+    (x.double().sum() + 2.0 * u.double().sum()).backward()
+    gxu = np.concatenate((np.ones((B, T, nx)), 2.0 * np.ones((B, T, nu))), 2)
+    dQ, dq = aso.backward(o["L"], o["xu"], gxu, chol_fail=True)
+    np.testing.assert_allclose(C.grad.diagonal(dim1=-2, dim2=-1).cpu().numpy()[ok], dQ[ok], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(c.grad.cpu().numpy()[ok], dq[ok], rtol=1e-3, atol=1e-5)

@@ -64,8 +64,23 @@ def test_non_spd_Q_is_flagged_per_problem(fam):
     st = info[:, 0].cpu().numpy()
     assert st[7] == _lib.DQP_STATUS_Q_NOT_PD and (np.delete(st, 7) == 0).all()
     assert bool(torch.isfinite(zhat[torch.arange(B) != 7]).all())
+    from diff_qp_mpc_amd import qp as qpmod
     with pytest.raises(RuntimeError, match="Q is not SPD"):                       # qp.py:86
+        # lazy by default: forward enqueues the check (no synchronisation), flush_checks() / backward / a later
+        # forward raises
         dqp.QPFunction(check_Q_spd=True, verbose=-1)(*[dev(a) for a in (Q, p, G, h, A, b)])
+        qpmod.flush_checks()
+    assert qpmod._pending == []
+    z = dqp.QPFunction(check_Q_spd=True, verbose=-1)(*[dev(a).requires_grad_() for a in (Q, p, G, h, A, b)])
+    with pytest.raises(RuntimeError, match="Q is not SPD"):                       # ... at backward
+        z.sum().backward()
+    qpmod.CHECKS = "sync"                                                         # as the reference: inside forward
+    try:
+        with pytest.raises(RuntimeError, match="Q is not SPD"):
+            dqp.QPFunction(check_Q_spd=True, verbose=-1)(*[dev(a) for a in (Q, p, G, h, A, b)])
+    finally:
+        qpmod.CHECKS = "lazy"
+    assert qpmod._pending == []
 
 
 def test_infeasible_problem_prints_warning_and_returns_best_iterate(fam, capsys):
@@ -77,7 +92,9 @@ def test_infeasible_problem_prints_warning_and_returns_best_iterate(fam, capsys)
     G[0, 1] = -G[0, 0]; h[0, 0] = -1.0; h[0, 1] = -1.0
     o = oracle.qp_forward(Q, p, G, h, A, b)
     assert o["best_resid"][0] > 1.0
+    from diff_qp_mpc_amd import qp as qpmod
     zhat = dqp.QPFunction(check_Q_spd=False, verbose=0)(*[dev(a) for a in (Q, p, G, h, A, b)])
+    qpmod.flush_checks()                                    # the warning is lazy too (qp.CHECKS)
     assert "Returning an inaccurate and potentially incorrect solution" in capsys.readouterr().out
     assert bool(torch.isfinite(zhat).all())
     ok = o["best_resid"] < 1e-8
@@ -85,6 +102,7 @@ def test_infeasible_problem_prints_warning_and_returns_best_iterate(fam, capsys)
     np.testing.assert_allclose(zhat.cpu().numpy()[ok], o["zhat"][ok], rtol=1e-6, atol=1e-8)
     # silent with verbose = -1, as the reference
     dqp.QPFunction(check_Q_spd=False, verbose=-1)(*[dev(a) for a in (Q, p, G, h, A, b)])
+    qpmod.flush_checks()
     assert capsys.readouterr().out == ""
 
 

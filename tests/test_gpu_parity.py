@@ -360,8 +360,10 @@ def test_not_spd_raises(dqp):
     Q, p, G, h, A, b = family_R(3, 4, 6, 4, 2)
     Q[2] = -Q[2]
     ins = [dev(a, grad=False) for a in (Q, p, G, h, A, b)]
+    from diff_qp_mpc_amd import qp as qpmod
     with pytest.raises(RuntimeError, match="Q is not SPD"):
         dqp.QPFunction(check_Q_spd=True, verbose=-1)(*ins)
+        qpmod.flush_checks()              # the check is lazy (qp.CHECKS): no synchronisation inside forward
 
 
 def test_cpu_tensors_fail_loudly(dqp):
