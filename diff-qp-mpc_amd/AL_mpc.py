@@ -35,6 +35,26 @@ def _detach(t):
     return t.detach() if t.requires_grad else t
 
 
+class _DeviceHistory:
+    """cost_lam_hist of a dqp_al_mpc_solve call: the reference's [[cost...], [lam...], [rho...]] lists (oldest first,
+    AL_mpc.py:283,308-310) as views of three device tensors; indexes and iterates like the list of lists."""
+
+    def __init__(self, cost, lam, rho):
+        self.cost, self.lam, self.rho = cost, lam, rho
+
+    def _lists(self):
+        return [list(self.cost.unbind(0)), list(self.lam.unbind(0)), [r.unsqueeze(1) for r in self.rho.unbind(0)]]
+
+    def __getitem__(self, i):
+        return self._lists()[i]
+
+    def __iter__(self):
+        return iter(self._lists())
+
+    def __len__(self):
+        return 3
+
+
 class MPC(Module):
     def __init__(self, n_state, n_ctrl, T, u_lower=None, u_upper=None, u_init=None, x_init=None,
                  al_iter=2, verbose=0, eps=1e-7, back_eps=1e-7, n_batch=None, linesearch_decay=0.2,
@@ -108,6 +128,24 @@ class MPC(Module):
         dense = self.n_state <= 8 and self.n_ctrl <= 2 and self.T * nt <= 128
         device_path = (_fused and FUSED_NEWTON_AL and isinstance(dx, DeviceDynamics) and (banded or dense)
                        and self.x_lower is None and self.u_lower.numel() == self.n_ctrl)
+        if (device_path and banded and al_utils.BANDED_NEWTON_AL and torch.is_tensor(self.rho_prev if rho_init is None else rho_init)
+                and dt == torch.float64):
+            # the whole solve -- start cost, warm start, al_iter x [Newton steps + line search, multiplier update] -- as one
+            # C-ABI call (dqp_al_mpc_solve); the history stays on the device as three tensors
+            lamda = self.lamda_prev.to(dt) if lamda_init is None else lamda_init
+            rho = self.rho_prev if rho_init is None else rho_init
+            prev = None if self.just_initialized else self._device_history()
+            xu, hc, hl, hr, resn, fail = al_utils.ALSolveDevice.apply(          # the iterate enters detached (AL_mpc.py:287)
+                x.detach(), u.detach(), x0.detach(), cost.C.to(dt), cost.c.to(dt), lamda.detach(), rho.detach(), dx,
+                self.u_lower, self.u_upper, self.al_iter, prev)
+            if CHECK_CHOLESKY and bool(fail.any()):
+                # a Cholesky factorisation broke down somewhere in the batch: the reference then switches the batch to an
+                # LU solve (al_utils.py:419-427) -- redo this solve on the general path
+                return self.al_solve(x_in, u_in, dx, dx_jac, x0_in, cost, lamda_init, rho_init, _fused=False)
+            self.cost_lam_hist = _DeviceHistory(hc, hl, hr)
+            self.lamda_prev, self.rho_prev, self.dyn_res_prev = hl[-1], hr[-1].unsqueeze(1), resn
+            self.just_initialized = False
+            return xu[:, :, :self.n_state].float(), xu[:, :, self.n_state:].float()                  # AL_mpc.py:319-320
         fail_flags = []
         x, u, x0 = x.to(dt), u.to(dt), x0.to(dt)
         lamda = self.lamda_prev.to(dt) if lamda_init is None else lamda_init
@@ -116,7 +154,7 @@ class MPC(Module):
             xu0 = torch.cat((x, u), dim=2)
             cost_start = self.compute_cost(xu0, cost.C.double(), cost.c.double())
             if not self.just_initialized:
-                hist = [torch.stack(h[::-1], dim=0) for h in self.cost_lam_hist]
+                hist = [torch.stack(list(h)[::-1], dim=0) for h in self.cost_lam_hist]
                 lamda, rho = al_utils.warm_start_al(x, lamda, rho, cost_start, *hist)
         Q, q = cost.C.to(dt), cost.c.to(dt)
         history = [[cost_start], [lamda], [rho]]
@@ -173,6 +211,15 @@ class MPC(Module):
         self.lamda_prev, self.rho_prev, self.dyn_res_prev = lamda, rho, dyn_res_clamp
         self.just_initialized = False
         return x.float(), u.float()                                        # AL_mpc.py:319-320
+
+    def _device_history(self):
+        """cost_lam_hist as the three device tensors dqp_al_mpc_solve reads: (K,B), (K,B,ncon), (K,B), oldest first"""
+        h = self.cost_lam_hist
+        if isinstance(h, _DeviceHistory):
+            return h.cost, h.lam, h.rho
+        B = self.n_batch
+        return (torch.stack([c.reshape(B) for c in h[0]]), torch.stack(list(h[1])),
+                torch.stack([r.reshape(B) for r in h[2]]))
 
     # ------------------------------------------------------------------ thin wrappers (AL_mpc.py:323-429)
     def merit_function(self, xu, Q, q, dx, x0, lamda, rho, grad=False):

@@ -50,7 +50,7 @@ SYMBOLS = ("dqp_version", "dqp_error_string", "dqp_workspace_bytes", "dqp_termin
            "dqp_al_newton_step", "dqp_al_chol_solve", "dqp_al_assemble", "dqp_al_merit",
            "dqp_al_newton_solve_bytes", "dqp_al_newton_solve",
            "dqp_al_outer_update", "dqp_al_banded_factor_bytes", "dqp_al_banded_newton_step", "dqp_al_banded_solve",
-           "dqp_al_banded_newton_step_jac", "dqp_al_lane_group",
+           "dqp_al_banded_newton_step_jac", "dqp_al_lane_group", "dqp_al_mpc_solve_bytes", "dqp_al_mpc_solve",
            "dqp_mpc_qp_stepped_workspace_bytes", "dqp_mpc_qp_stepped_termination_bytes", "dqp_mpc_qp_forward_stepped", "dqp_trace_begin", "dqp_trace_end",
            "dqp_dyn_sizes", "dqp_dyn_step", "dqp_dyn_jacobian", "dqp_dyn_forward_dynamics",
            "dqp_dyn_forward_derivatives")
@@ -157,6 +157,11 @@ def load():
     lib.dqp_al_banded_newton_step_jac.argtypes = [ctypes.POINTER(dqp_al_mpc_dims)] + [_dp] * 15
     lib.dqp_al_banded_solve.restype = ctypes.c_int
     lib.dqp_al_banded_solve.argtypes = [ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int] + [_dp] * 4
+    lib.dqp_al_mpc_solve_bytes.restype = ctypes.c_size_t
+    lib.dqp_al_mpc_solve_bytes.argtypes = [ctypes.POINTER(dqp_al_mpc_dims)]
+    lib.dqp_al_mpc_solve.restype = ctypes.c_int
+    lib.dqp_al_mpc_solve.argtypes = ([ctypes.POINTER(dqp_al_mpc_dims), ctypes.c_int, ctypes.c_double, ctypes.c_int32, ctypes.c_int32]
+                                     + [_dp] * 12 + [ctypes.c_int32] + [_dp] * 10)
     lib.dqp_al_lane_group.restype = ctypes.c_int
     lib.dqp_al_lane_group.argtypes = [ctypes.c_int]
     lib.dqp_mpc_qp_stepped_workspace_bytes.restype = ctypes.c_size_t

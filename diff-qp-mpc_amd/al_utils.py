@@ -530,6 +530,55 @@ class NewtonALDevice(torch.autograd.Function):
         return (None,) * 4 + (g * x.to(x_grad.dtype), g) + (None,) * 5      # al_utils.py:482-485
 
 
+class ALSolveDevice(torch.autograd.Function):
+    """AL_mpc.MPC.al_solve for a dynamics.DeviceDynamics as ONE C-ABI call (dqp_al_mpc_solve: start cost, warm
+    start, al_iter x [four Newton steps with line search, multiplier / penalty update], no host involvement), and
+    NewtonAL's backward through the last block-tridiagonal factor.  `prev` = (cost, lam, rho) history tensors of
+    the previous call or None.  Returns xu (B,T,nt) and, non-differentiable, the new history (cost (K,B), lam
+    (K,B,ncon), rho (K,B)), |res_clamp| (B) and the per-AL-iteration Cholesky-failure flags (int32)."""
+
+    @staticmethod
+    def forward(ctx, x_init, u_init, x0, Q, q, lam, rho, dyn, u_lower, u_upper, al_iter, prev):
+        lib = _lib.load()
+        B, T, n = x_init.shape
+        m = u_init.shape[-1]
+        nt, ncon = n + m, T * n + 2 * T * m
+        dev = x0.device
+        d64 = lambda t: t.detach().double().contiguous()
+        keep = [d64(x_init), d64(u_init), d64(x0), d64(Q), d64(q), d64(u_lower).reshape(-1), d64(u_upper).reshape(-1),
+                d64(lam), d64(rho).reshape(B)]
+        _need_gpu(keep[0])
+        pc, pl, pr = (d64(t) for t in prev) if prev is not None else (None, None, None)
+        n_prev = pc.shape[0] if prev is not None else 0
+        dims = _lib.dqp_al_mpc_dims(B, n, m, T)
+        kw = dict(dtype=torch.float64, device=dev)
+        xu = torch.empty(B, T, nt, **kw)
+        hc, hl, hr = torch.empty(al_iter + 1, B, **kw), torch.empty(al_iter + 1, B, ncon, **kw), torch.empty(al_iter + 1, B, **kw)
+        resn, status = torch.empty(B, **kw), torch.empty(B, **kw)
+        L = torch.empty(int(lib.dqp_al_banded_factor_bytes(ctypes.byref(dims), dyn.id)) // 8, **kw)
+        fail = torch.empty(al_iter, dtype=torch.int32, device=dev)
+        ws = torch.empty(int(lib.dqp_al_mpc_solve_bytes(ctypes.byref(dims))) // 8 + 1, **kw)
+        with torch.cuda.device(dev):
+            rc = lib.dqp_al_mpc_solve(ctypes.byref(dims), dyn.id, dyn.dt, al_iter, MAX_NEWTON_STEPS, *[_ptr(t) for t in keep],
+                                      _ptr(pc), _ptr(pl), _ptr(pr), n_prev, _ptr(xu), _ptr(hc), _ptr(hl), _ptr(hr), _ptr(resn),
+                                      _ptr(L), _ptr(status), _ptr(fail), _ptr(ws), _stream(dev))
+        _lib.check(rc, "dqp_al_mpc_solve")
+        ctx.dims, ctx.dyn_id = dims, dyn.id
+        ctx.save_for_backward(L, xu)
+        ctx.mark_non_differentiable(hc, hl, hr, resn, fail)
+        return xu, hc, hl, hr, resn, fail
+
+    @staticmethod
+    def backward(ctx, x_grad, *unused):
+        L, x = ctx.saved_tensors
+        rhs = x_grad.detach().double().contiguous()
+        g = torch.empty_like(rhs)
+        with torch.cuda.device(rhs.device):
+            rc = _lib.load().dqp_al_banded_solve(ctypes.byref(ctx.dims), ctx.dyn_id, _ptr(L), _ptr(rhs), _ptr(g), _stream(rhs.device))
+        _lib.check(rc, "dqp_al_banded_solve")
+        return (None,) * 3 + (g * x, g) + (None,) * 7                      # al_utils.py:482-485
+
+
 def outer_update_device(xu, x0, lam, rho, Q, q, dyn, u_lower, u_upper):
     """AL_mpc.py:296-307 in one launch (dqp_al_outer_update): -> (lam_new, cost (B), |res_clamp| (B))."""
     lib = _lib.load()

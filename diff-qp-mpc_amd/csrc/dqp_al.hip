@@ -849,6 +849,7 @@ struct OutP {
     double *lam_new, *cost, *resn;
     double dt;
     int B, n, m, T, dyn;
+    double *rho_next;       // optional: rho * 10 (AL_mpc.py:307), for the next AL iteration of dqp_al_mpc_solve
 };
 
 // Between two AL iterations (qpth/AL_mpc.py:296-307): res = constraint residual at the new iterate,
@@ -899,7 +900,56 @@ __global__ __launch_bounds__(256) void al_outer_kernel(OutP P)
     }
     cost = dqp::r16::row_sum(cost);
     rn2 = dqp::r16::row_sum(rn2);
-    if (live && r == 0) { P.cost[b] = cost; P.resn[b] = sqrt(rn2); }
+    if (live && r == 0) {
+        P.cost[b] = cost; P.resn[b] = sqrt(rn2);
+        if (P.rho_next) P.rho_next[b] = rho * 10.0;
+    }
+}
+
+// Head of AL_mpc.MPC.al_solve (AL_mpc.py:254-283): xu = [x_init | u_init], cost_start = compute_cost(xu), the warm
+// start of the multipliers / penalty from the previous call's history (al_utils.warm_start_al, al_utils.py:16-34:
+// the newest stored AL iterate whose cost was already below cost_start, the newest one if none was; lam rescaled to
+// that iterate's norm), and entry 0 of this call's history.  16 lanes per problem.
+struct StartP {
+    const double *x_init, *u_init, *Qd, *q, *lam_in, *rho_in;
+    const double *hist_cost, *hist_lam, *hist_rho;      // previous call, oldest first: (K, B), (K, B, ncon), (K, B); or NULL
+    double *xu, *cost0, *lam0, *rho0;
+    int B, n, m, T, K;
+};
+__global__ __launch_bounds__(256) void al_start_kernel(StartP P)
+{
+    const int n = P.n, m = P.m, nt = n + m, T = P.T, ncon = T * n + 2 * T * m;
+    const long long item = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int r = threadIdx.x & 15;
+    const long long b = item < P.B ? item : P.B - 1;
+    const bool live = item < P.B;
+    double *xu = P.xu + b * (long long)T * nt;
+    const double *Qd = P.Qd + b * (long long)T * nt, *q = P.q + b * (long long)T * nt;
+    double quad = 0.0, lin = 0.0;
+    for (int e = r; e < T * nt; e += 16) {
+        const int t = e / nt, j = e - t * nt;
+        const double v = j < n ? P.x_init[(b * T + t) * n + j] : P.u_init[(b * T + t) * m + (j - n)];
+        if (live) xu[e] = v;
+        quad += v * Qd[e] * v;
+        lin += q[e] * v;
+    }
+    const double cost0 = 0.5 * dqp::r16::row_sum(quad) + dqp::r16::row_sum(lin);       // al_utils.compute_cost, diagonal cost
+    const double *lam = P.lam_in + b * (long long)ncon;
+    double scale = 1.0, rho = P.rho_in[b];
+    if (P.K > 0) {
+        int pick = P.K - 1;                                   // torch.max of an all-False column: index 0 = the newest
+        for (int k = P.K - 1; k >= 0; --k)
+            if (P.hist_cost[(long long)k * P.B + b] < cost0) { pick = k; break; }
+        const double *lh = P.hist_lam + ((long long)pick * P.B + b) * ncon;
+        double nh = 0.0, nl = 0.0;
+        for (int e = r; e < ncon; e += 16) { nh += lh[e] * lh[e]; nl += lam[e] * lam[e]; }
+        scale = sqrt(dqp::r16::row_sum(nh)) / sqrt(dqp::r16::row_sum(nl));
+        rho = P.hist_rho[(long long)pick * P.B + b];
+    }
+    if (!live) return;
+    double *l0 = P.lam0 + b * (long long)ncon;
+    for (int e = r; e < ncon; e += 16) l0[e] = P.K > 0 ? lam[e] * scale : lam[e];
+    if (r == 0) { P.cost0[b] = cost0; P.rho0[b] = rho; }
 }
 
 int launch_outer(const OutP &P, hipStream_t st)
@@ -1156,8 +1206,47 @@ dqp_al_outer_update(const dqp_al_mpc_dims *d, int dyn_id, double dt, const doubl
     if (!xu || !x0 || !lam || !rho || !Qdiag || !q || !u_lower || !u_upper || !lam_new || !cost || !res_norm)
         return DQP_ERR_BAD_ARG;
     OutP P = {xu, x0, lam, rho, Qdiag, q, u_lower, u_upper, lam_new, cost, res_norm, dt, d->nbatch, d->n_state,
-              d->n_ctrl, d->T, dyn_id};
+              d->n_ctrl, d->T, dyn_id, nullptr};
     return launch_outer(P, (hipStream_t)stream);
+}
+
+__attribute__((visibility("default"))) size_t dqp_al_mpc_solve_bytes(const dqp_al_mpc_dims *d)
+{
+    return dqp_al_newton_solve_bytes(d, 1);
+}
+
+__attribute__((visibility("default"))) int
+dqp_al_mpc_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t al_iter, int32_t newton_steps,
+                 const double *x_init, const double *u_init, const double *x0, const double *Qdiag, const double *q,
+                 const double *u_lower, const double *u_upper, const double *lam_in, const double *rho_in,
+                 const double *prev_cost, const double *prev_lam, const double *prev_rho, int32_t n_prev,
+                 double *xu, double *hist_cost, double *hist_lam, double *hist_rho, double *res_norm, double *factor,
+                 double *status, int32_t *fail, void *workspace, void *stream)
+{
+    if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2 || al_iter < 1 || newton_steps < 1 || n_prev < 0)
+        return DQP_ERR_BAD_ARG;
+    if (d->nbatch == 0) return DQP_OK;
+    if (!x_init || !u_init || !x0 || !Qdiag || !q || !u_lower || !u_upper || !lam_in || !rho_in || !xu || !hist_cost ||
+        !hist_lam || !hist_rho || !res_norm || !factor || !fail || !workspace)
+        return DQP_ERR_BAD_ARG;
+    if (n_prev > 0 && (!prev_cost || !prev_lam || !prev_rho)) return DQP_ERR_BAD_ARG;
+    if (d->n_state > 12 || d->n_state + d->n_ctrl > 16) return DQP_ERR_TOO_LARGE;
+    const int B = d->nbatch, n = d->n_state, m = d->n_ctrl, T = d->T;
+    const long long ncon = (long long)T * n + 2LL * T * m;
+    hipStream_t st = (hipStream_t)stream;
+    StartP S = {x_init, u_init, Qdiag, q, lam_in, rho_in, prev_cost, prev_lam, prev_rho, xu, hist_cost, hist_lam, hist_rho,
+                B, n, m, T, n_prev};
+    DQP_LAUNCH(al_start_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, S);
+    for (int i = 0; i < al_iter; ++i) {
+        const double *lam = hist_lam + (long long)i * B * ncon, *rho = hist_rho + (long long)i * B;
+        int rc = dqp_al_newton_solve(d, dyn_id, dt, newton_steps, 1, x0, Qdiag, q, lam, rho, u_lower, u_upper, xu, factor,
+                                     status, fail + i, workspace, stream);
+        if (rc) return rc;
+        OutP O = {xu, x0, lam, rho, Qdiag, q, u_lower, u_upper, hist_lam + (long long)(i + 1) * B * ncon,
+                  hist_cost + (long long)(i + 1) * B, res_norm, dt, B, n, m, T, dyn_id, hist_rho + (long long)(i + 1) * B};
+        if ((rc = launch_outer(O, st)) != DQP_OK) return rc;
+    }
+    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
 }
 
 }  // extern "C"

@@ -435,6 +435,29 @@ int dqp_al_outer_update(const dqp_al_mpc_dims *dims, int dyn_id, double dt, cons
                         double *res_norm, void *stream);
 
 /*
+ * Replaces: AL_mpc.MPC.al_solve for a registered device model (qpth/AL_mpc.py:254-321) as ONE call with no host
+ * involvement: xu = [x_init | u_init]; cost_start; the warm start of (lam, rho) from the previous call's history
+ * (al_utils.warm_start_al, al_utils.py:16-34; n_prev = 0 after reinitialize()); then al_iter times
+ * [dqp_al_newton_solve (block-tridiagonal, newton_steps Newton steps with the 20-candidate line search) ->
+ * lam <- clamp(lam + rho res), cost, |res_clamp|, rho <- 10 rho (AL_mpc.py:296-307)].
+ * History layout, oldest first as the reference keeps it: hist_cost (al_iter+1, B), hist_lam (al_iter+1, B, ncon),
+ * hist_rho (al_iter+1, B), entry 0 = the (warm-started) start, entry i+1 = after AL iteration i; the final
+ * multipliers / penalty are the last entry (what the reference stores in lamda_prev / rho_prev).  prev_* = the
+ * hist_* arrays of the previous call (n_prev entries).  xu (B, T, n+m) out; res_norm (B) = |res_clamp| of the last
+ * iterate; factor (dqp_al_banded_factor_bytes) = the block-tridiagonal factor of the LAST Newton step, for
+ * dqp_al_banded_solve (NewtonAL.backward); fail (al_iter int32): set where a Cholesky pivot was not positive in
+ * that AL iteration (the reference then solves by LU: redo the call on the general path); workspace:
+ * dqp_al_mpc_solve_bytes.  ncon = T n_state + 2 T n_ctrl.  n_state + n_ctrl <= 16, n_state <= 12.
+ */
+size_t dqp_al_mpc_solve_bytes(const dqp_al_mpc_dims *dims);
+int dqp_al_mpc_solve(const dqp_al_mpc_dims *dims, int dyn_id, double dt, int32_t al_iter, int32_t newton_steps,
+                     const double *x_init, const double *u_init, const double *x0, const double *Qdiag, const double *q,
+                     const double *u_lower, const double *u_upper, const double *lam_in, const double *rho_in,
+                     const double *prev_cost, const double *prev_lam, const double *prev_rho, int32_t n_prev,
+                     double *xu, double *hist_cost, double *hist_lam, double *hist_rho, double *res_norm, double *factor,
+                     double *status, int32_t *fail, void *workspace, void *stream);
+
+/*
  * The same Newton step with the MPC structure exploited (`banded` != 0 above uses it): the Hessian
  * diag(Q) + rho Jc^T Jc is block tridiagonal in the knots, so linearisation, gradient, block Cholesky
  * and the solve run as ONE launch with every knot in registers (4 problems per wavefront), O(T (n+m)^3)
