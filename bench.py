@@ -436,12 +436,19 @@ class RobotAL(Workload):
         self.ctrl = AL_mpc.MPC(nx, nu, T, u_lower=lo, u_upper=hi, n_batch=B, verbose=0, solver_type="dense",
                                dtype=torch.float64, eps=1e-5, exit_unconverged=False, backprop=False)
         self.mask = torch.ones(B, T, 1, device=dev)
+        self.ctrl.mask = self.mask
         self.u = None
+        self.graphed = None
+        if getattr(args, "graph", False):      # the cold call captured as two hipGraphs (AL_mpc.GraphedMPC)
+            self.graphed = AL_mpc.GraphedMPC(self.ctrl, (self.x0, self.C, self.c), dyn, x_init=self.x_ref, u_init=self.u_ref)
 
     def step(self, gather=None):
-        self.ctrl.reinitialize(self.x0, self.mask)
-        self.ctrl.x_init, self.ctrl.u_init = self.x_ref, self.u_ref
-        x, u = self.ctrl(self.x0, self.al_utils.QuadCost(self.C, self.c), self.dyn, self.dyn.jac)
+        if self.graphed is not None:
+            x, u = self.graphed(self.x0, self.C, self.c)
+        else:
+            self.ctrl.reinitialize(self.x0, self.mask)
+            self.ctrl.x_init, self.ctrl.u_init = self.x_ref, self.u_ref
+            x, u = self.ctrl(self.x0, self.al_utils.QuadCost(self.C, self.c), self.dyn, self.dyn.jac)
         self.x, self.u = x.detach(), u.detach().double().contiguous()
         work = gather(self.u) if gather else None
         self.C.grad = self.c.grad = None
@@ -517,12 +524,20 @@ class CartpoleAL(RobotAL):
     metric = "trajectories/sec (AL_mpc.MPC fwd+bwd), cartpole-1 batch=4096 T=20"
 
     def __init__(self, torch, dev, rank, world, args):
-        super().__init__(torch, dev, rank, world, args, "cartpole1l", 4096, 20)
+        # --robot / --T / --batch: the same call at other sizes (the reference trains at --bsz 128, deqmpc/train.py:46)
+        robot = getattr(args, "robot", None) or "cartpole1l"
+        super().__init__(torch, dev, rank, world, args, robot, getattr(args, "batch", None) or 4096, getattr(args, "T", None) or 20)
+        if (robot, self.B, self.T) != ("cartpole1l", 4096, 20):
+            self.metric = "trajectories/sec (AL_mpc.MPC fwd+bwd), %s batch=%d T=%d" % (robot, self.B, self.T)
 
     def describe(self, world):
-        return {"workload": "BASELINE configs[2]: AL_mpc.MPC inner loop on cartpole-1 (n 4, m 1), T 20, 2 AL iterations x 4 "
-                            "Newton steps + backward, setup as tests/golden/make_golden_cfg3.py; B=4096/GPU",
-                "global_batch": world * self.B, "n_state": 4, "n_ctrl": 1, "T": 20, "parallelism": "batch-shard x%d" % world}
+        std = (self.robot, self.B, self.T) == ("cartpole1l", 4096, 20)
+        return {"workload": ("BASELINE configs[2]: " if std else "variant of configs[2]: ") +
+                            "AL_mpc.MPC inner loop on %s (n %d, m %d), T %d, 2 AL iterations x 4 Newton steps + backward, setup as "
+                            "tests/golden/make_golden_cfg3.py; B=%d/GPU%s" % (self.robot, self.nx, self.nu, self.T, self.B,
+                                                                             ", cold call replayed as hipGraphs" if self.graphed else ""),
+                "global_batch": world * self.B, "n_state": self.nx, "n_ctrl": self.nu, "T": self.T,
+                "parallelism": "batch-shard x%d" % world}
 
 
 class QuadrotorAL(RobotAL):
@@ -558,7 +573,7 @@ class DEQMPCTrain(Workload):
         from diff_qp_mpc_amd.dynamics import DeviceDynamics
         assert self.GLOBAL_B % world == 0
         self.torch, self.policies = torch, policies
-        B = self.B = self.units = int(os.environ.get("DQP_BENCH_CFG5_BATCH", self.GLOBAL_B)) // world
+        B = self.B = self.units = int(getattr(args, "batch", None) or os.environ.get("DQP_BENCH_CFG5_BATCH", self.GLOBAL_B)) // world
         T, self.deq_iter = 5, 6
         self.T = T
         self.dyn = dyn = DeviceDynamics("cartpole2l", dt=0.03)
@@ -570,7 +585,8 @@ class DEQMPCTrain(Workload):
                                Q=torch.ones(nx), R=1e-2 * torch.ones(nu), dtype="double", device=str(dev))
         torch.manual_seed(0)
         self.policy = policies.DEQMPCPolicy(a, env)
-        self.opt = torch.optim.Adam(self.policy.model.parameters(), lr=1e-4)
+        self.graph = bool(getattr(args, "graph", False))
+        self.opt = torch.optim.Adam(self.policy.model.parameters(), lr=1e-4, capturable=self.graph)
         gen = torch.Generator(device=dev).manual_seed(rank)
         self.x = torch.rand(B, nx, device=dev, generator=gen) - 0.5
         self.gs = self.x[:, None, :] * torch.linspace(1, 0, T, device=dev)[None, :, None]
@@ -578,8 +594,16 @@ class DEQMPCTrain(Workload):
         self.mask = torch.ones(B, T, device=dev)
         self.group = dist.group.WORLD if world > 1 else None
         self.loss = None
+        self.graphed = None
+        if self.graph:      # the whole training step as one hipGraph (policies.GraphedTrainStep)
+            self.graphed = policies.GraphedTrainStep(self.policy, self.opt, self.x, self.gs, self.ga, self.mask, group=self.group)
+        if B * world != self.GLOBAL_B:
+            self.metric = "trajectories/sec (DEQ-MPC training step), cartpole-2 batch=%d T=5 deq_iter=6" % (B * world)
 
     def step(self, gather=None):
+        if self.graphed is not None:
+            self.loss, _, _ = self.graphed(self.x, self.gs, self.ga, self.mask)
+            return
         self.loss, _, _ = self.policies.train_step(self.policy, self.opt, self.x, self.gs, self.ga, self.mask, group=self.group)
 
     def kernel_bytes(self, kernel):
@@ -626,6 +650,10 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=1, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=None, help="configs 3 and 5: another batch size (per GPU for 3, global for 5)")
+    ap.add_argument("--robot", default=None, help="config 3: another registered model (cartpole2l, pendulum_euler, ...)")
+    ap.add_argument("--T", type=int, default=None, help="config 3: another horizon")
+    ap.add_argument("--graph", action="store_true", help="configs 3-5: replay the call / the training step as hipGraphs")
     ap.add_argument("--termination", choices=["batch", "per_problem"], default="batch",
                     help="config 1: mode of the headline number (default: the parity-safe batch rule)")
     args = ap.parse_args(argv)
@@ -679,6 +707,9 @@ def main(argv=None):
             dist.init_process_group(backend)
 
     from diff_qp_mpc_amd import _lib
+    if os.environ.get("DQP_BENCH_AL_PER_SOLVE_CALLS") == "1":       # A/B: round 2's host loop around the Newton solves
+        from diff_qp_mpc_amd import AL_mpc
+        AL_mpc.ONE_CALL_SOLVE = False
     wl = WORKLOADS[args.config](torch, dev, rank, world, args)
 
     gathered = {}
@@ -711,10 +742,12 @@ def main(argv=None):
 
     # per-kernel times of the same step, HIP events on the launch stream (the library's own trace)
     tsteps = max(1, min(args.steps, 20))
+    graphed, wl.graphed = getattr(wl, "graphed", None), None       # graph replays launch nothing through the library: trace the eager step
     with _lib.trace(200000) as tr:
         for _ in range(tsteps):
             wl.step(None)
         torch.cuda.synchronize()
+    wl.graphed = graphed
     kern = {short_kernel(k): (c / tsteps, ms) for k, (c, ms) in tr.by_kernel().items()}
     total_kernel_ms = sum(c * ms for c, ms in kern.values())
 

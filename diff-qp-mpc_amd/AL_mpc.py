@@ -19,6 +19,9 @@ from .dynamics import DeviceDynamics
 
 # registered device models run NewtonAL's four Newton steps as one C-ABI call (no Python in between)
 FUSED_NEWTON_AL = True
+# registered device models with a block-tridiagonal kernel: the whole al_solve (warm start, al_iter x [Newton steps,
+# multiplier update]) as one C-ABI call, dqp_al_mpc_solve; False: one call per Newton solve and outer update (round 2)
+ONE_CALL_SOLVE = True
 # one host synchronisation per al_solve to look at the Cholesky-failure flags of the device path
 # (False: never look -- needed to capture a call in a hipGraph; a failed factorisation then leaves its
 # problem at the last accepted iterate)
@@ -88,6 +91,7 @@ class MPC(Module):
         self.rho_prev = 1.0
         self.lamda_prev = torch.zeros(n_batch, self.neq + self.nineq, dtype=self.u_upper.dtype, device=self.u_upper.device)
         self.dyn_res_prev = 1000000
+        self.fail_log = []
         self.mask = torch.ones(n_batch, T, 1, dtype=self.u_upper.dtype, device=self.u_upper.device)
 
     # ------------------------------------------------------------------ AL_mpc.py:198-252
@@ -128,7 +132,7 @@ class MPC(Module):
         dense = self.n_state <= 8 and self.n_ctrl <= 2 and self.T * nt <= 128
         device_path = (_fused and FUSED_NEWTON_AL and isinstance(dx, DeviceDynamics) and (banded or dense)
                        and self.x_lower is None and self.u_lower.numel() == self.n_ctrl)
-        if (device_path and banded and al_utils.BANDED_NEWTON_AL and torch.is_tensor(self.rho_prev if rho_init is None else rho_init)
+        if (ONE_CALL_SOLVE and device_path and banded and al_utils.BANDED_NEWTON_AL and torch.is_tensor(self.rho_prev if rho_init is None else rho_init)
                 and dt == torch.float64):
             # the whole solve -- start cost, warm start, al_iter x [Newton steps + line search, multiplier update] -- as one
             # C-ABI call (dqp_al_mpc_solve); the history stays on the device as three tensors
@@ -138,6 +142,7 @@ class MPC(Module):
             xu, hc, hl, hr, resn, fail = al_utils.ALSolveDevice.apply(          # the iterate enters detached (AL_mpc.py:287)
                 x.detach(), u.detach(), x0.detach(), cost.C.to(dt), cost.c.to(dt), lamda.detach(), rho.detach(), dx,
                 self.u_lower, self.u_upper, self.al_iter, prev)
+            self.fail_log.append(fail)          # per-AL-iteration Cholesky-failure flags of the calls since reinitialize()
             if CHECK_CHOLESKY and bool(fail.any()):
                 # a Cholesky factorisation broke down somewhere in the batch: the reference then switches the batch to an
                 # LU solve (al_utils.py:419-427) -- redo this solve on the general path
@@ -285,3 +290,60 @@ class MPC(Module):
         self.dyn_res_prev = 1000000
         self.just_initialized = True
         self.mask = mask
+        self.fail_log = []
+
+
+class GraphedMPC:
+    """One COLD call of an AL_mpc.MPC -- reinitialize() + forward -- on a registered device model captured as two
+    hipGraphs (forward; backward through NewtonAL's implicit derivative), like qp_wrapper.GraphedMPC: the solve is C-ABI
+    calls that only enqueue on the current stream.  Shapes and the batch size are frozen at capture; inputs are copied into
+    the graph's static buffers.  The Cholesky-failure flags are not looked at inside the graph (CHECK_CHOLESKY is off for
+    the captured call): `failed()` reads those of the last replay.
+
+        g = GraphedMPC(ctrl, (x0, C, c), dyn, x_init=x_ref, u_init=u_ref);   x, u = g(x0, C, c)
+    """
+
+    def __init__(self, ctrl, sample_inputs, dyn, x_init=None, u_init=None, warmup=3):
+        global CHECK_CHOLESKY
+        from .qp_wrapper import _GraphReplay
+        self._replay = _GraphReplay
+        self.ctrl, self.dyn = ctrl, dyn
+        self.x_init, self.u_init = x_init, u_init
+        self.static_inputs = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in sample_inputs)
+        check, CHECK_CHOLESKY = CHECK_CHOLESKY, False
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    outs = self._call(*self.static_inputs)
+                    torch.autograd.grad(outs, self._grad_inputs(), tuple(torch.ones_like(o) for o in outs), allow_unused=True)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            pool = torch.cuda.graph_pool_handle()
+            self.fwd_graph, self.bwd_graph = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.fwd_graph, pool=pool):
+                self.static_outputs = self._call(*self.static_inputs)
+                self._flags = list(ctrl.fail_log)
+            self.static_grad_outputs = tuple(torch.zeros_like(o) for o in self.static_outputs)
+            with torch.cuda.graph(self.bwd_graph, pool=pool):
+                gi = torch.autograd.grad(self.static_outputs, self._grad_inputs(), self.static_grad_outputs, allow_unused=True)
+        finally:
+            CHECK_CHOLESKY = check
+        it = iter(gi)
+        self.static_grad_inputs = tuple(next(it) if t.requires_grad else None for t in self.static_inputs)
+
+    def _grad_inputs(self):
+        return tuple(t for t in self.static_inputs if t.requires_grad)
+
+    def _call(self, x0, C, c):
+        ctrl = self.ctrl
+        ctrl.reinitialize(x0, ctrl.mask)
+        ctrl.x_init, ctrl.u_init = self.x_init, self.u_init
+        return ctrl(x0, QuadCost(C, c), self.dyn, self.dyn.jac)
+
+    def __call__(self, *inputs):
+        return self._replay.apply(self, *inputs)
+
+    def failed(self):
+        return any(bool(f.any()) for f in self._flags)

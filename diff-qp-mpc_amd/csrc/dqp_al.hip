@@ -915,6 +915,8 @@ struct StartP {
     const double *hist_cost, *hist_lam, *hist_rho;      // previous call, oldest first: (K, B), (K, B, ncon), (K, B); or NULL
     double *xu, *cost0, *lam0, *rho0;
     int B, n, m, T, K;
+    int32_t *fail;          // al_iter Cholesky-failure flags, cleared here
+    int nfail;
 };
 __global__ __launch_bounds__(256) void al_start_kernel(StartP P)
 {
@@ -923,6 +925,7 @@ __global__ __launch_bounds__(256) void al_start_kernel(StartP P)
     const int r = threadIdx.x & 15;
     const long long b = item < P.B ? item : P.B - 1;
     const bool live = item < P.B;
+    if (blockIdx.x == 0 && (int)threadIdx.x < P.nfail) P.fail[threadIdx.x] = 0;
     double *xu = P.xu + b * (long long)T * nt;
     const double *Qd = P.Qd + b * (long long)T * nt, *q = P.q + b * (long long)T * nt;
     double quad = 0.0, lin = 0.0;
@@ -1102,11 +1105,26 @@ __attribute__((visibility("default"))) size_t dqp_al_newton_solve_bytes(const dq
     return ((size_t)d->nbatch * al_solve_doubles(d->n_state, d->n_ctrl, d->T) + 2) * sizeof(double);
 }
 
+static int newton_solve_impl(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_steps, int32_t banded,
+                             const double *x0, const double *Qdiag, const double *q, const double *lam, const double *rho,
+                             const double *u_lower, const double *u_upper, double *xu, double *L, double *status,
+                             int32_t *fail, void *workspace, void *stream, bool clear_fail);
+
 __attribute__((visibility("default"))) int
 dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_steps, int32_t banded,
                     const double *x0, const double *Qdiag, const double *q, const double *lam, const double *rho,
                     const double *u_lower, const double *u_upper, double *xu, double *L, double *status,
                     int32_t *fail, void *workspace, void *stream)
+{
+    return newton_solve_impl(d, dyn_id, dt, n_steps, banded, x0, Qdiag, q, lam, rho, u_lower, u_upper, xu, L, status, fail,
+                             workspace, stream, true);
+}
+
+// clear_fail = false: the caller's own kernel zeroed the flag (dqp_al_mpc_solve: al_start_kernel clears all of them)
+static int newton_solve_impl(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_steps, int32_t banded,
+                             const double *x0, const double *Qdiag, const double *q, const double *lam, const double *rho,
+                             const double *u_lower, const double *u_upper, double *xu, double *L, double *status,
+                             int32_t *fail, void *workspace, void *stream, bool clear_fail)
 {
     if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2 || n_steps < 1) return DQP_ERR_BAD_ARG;
     if (d->nbatch == 0) return DQP_OK;
@@ -1126,7 +1144,7 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
         double *merit = w;         w += (size_t)20 * B;
         double *merit_cur = w;     w += (size_t)B;
         int32_t *info = (int32_t *)w;
-        if (hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
+        if (clear_fail && hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
         LsAP Lp = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit_cur, dt, B, n, m, T, 0, dyn_id};
         int rc0 = launch_ls(Lp, st);                                    // merit at the start
         if (rc0) return rc0;
@@ -1160,7 +1178,7 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
     double *merit = w;         w += (size_t)20 * B;
     double *merit_cur = w;     w += (size_t)B;
     int32_t *info = (int32_t *)w;
-    if (hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
+    if (clear_fail && hipMemsetAsync(fail, 0, sizeof(int32_t), st) != hipSuccess) return DQP_ERR_LAUNCH;
     LsAP Lp = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit_cur, dt, B, n, m, T, 0, dyn_id};
     rc = launch_ls(Lp, st);                                             // merit at the start
     if (rc) return rc;
@@ -1223,7 +1241,8 @@ dqp_al_mpc_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t al_ite
                  double *xu, double *hist_cost, double *hist_lam, double *hist_rho, double *res_norm, double *factor,
                  double *status, int32_t *fail, void *workspace, void *stream)
 {
-    if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2 || al_iter < 1 || newton_steps < 1 || n_prev < 0)
+    if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2 || al_iter < 1 || al_iter > 256 || newton_steps < 1 ||
+        n_prev < 0)
         return DQP_ERR_BAD_ARG;
     if (d->nbatch == 0) return DQP_OK;
     if (!x_init || !u_init || !x0 || !Qdiag || !q || !u_lower || !u_upper || !lam_in || !rho_in || !xu || !hist_cost ||
@@ -1235,12 +1254,12 @@ dqp_al_mpc_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t al_ite
     const long long ncon = (long long)T * n + 2LL * T * m;
     hipStream_t st = (hipStream_t)stream;
     StartP S = {x_init, u_init, Qdiag, q, lam_in, rho_in, prev_cost, prev_lam, prev_rho, xu, hist_cost, hist_lam, hist_rho,
-                B, n, m, T, n_prev};
+                B, n, m, T, n_prev, fail, al_iter};
     DQP_LAUNCH(al_start_kernel, dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, S);
     for (int i = 0; i < al_iter; ++i) {
         const double *lam = hist_lam + (long long)i * B * ncon, *rho = hist_rho + (long long)i * B;
-        int rc = dqp_al_newton_solve(d, dyn_id, dt, newton_steps, 1, x0, Qdiag, q, lam, rho, u_lower, u_upper, xu, factor,
-                                     status, fail + i, workspace, stream);
+        int rc = newton_solve_impl(d, dyn_id, dt, newton_steps, 1, x0, Qdiag, q, lam, rho, u_lower, u_upper, xu, factor,
+                                   status, fail + i, workspace, stream, false);
         if (rc) return rc;
         OutP O = {xu, x0, lam, rho, Qdiag, q, u_lower, u_upper, hist_lam + (long long)(i + 1) * B * ncon,
                   hist_cost + (long long)(i + 1) * B, res_norm, dt, B, n, m, T, dyn_id, hist_rho + (long long)(i + 1) * B};

@@ -230,3 +230,64 @@ def train_step(policy, optimizer, x0, gt_states, gt_actions, gt_mask, group=None
     allreduce_gradients(policy.model, group)
     optimizer.step()
     return loss.detach(), loss_end.detach(), dyn_res
+
+
+class GraphedTrainStep:
+    """train_step captured as ONE hipGraph: deq_iter x [DEQLayer -> AL_mpc.MPC solve], the loss, the backward through
+    the solvers and -- with a capturable optimiser and no process group -- the optimiser step.  Every solver call is
+    a C-ABI call that only enqueues on the current stream (dqp_al_mpc_solve, dqp_al_banded_solve), so a training step
+    becomes one graph launch instead of several hundred Python-dispatched ones: this is the small-batch path (the
+    reference trains at --bsz 128, deqmpc/train.py:46, where a step is launch-bound).  Shapes and the batch size are
+    frozen at capture; `__call__` copies the batch into the graph's static inputs.  With a process group the graph
+    ends after backward and the flat gradient all-reduce and the optimiser step run eagerly after the replay.
+    The Cholesky-failure flags cannot be looked at inside a graph (AL_mpc.CHECK_CHOLESKY is off for the captured
+    calls): `failed()` reads the flags of the last replay (one synchronisation) -- a set flag means that step's
+    solve should be redone eagerly."""
+
+    def __init__(self, policy, optimizer, x0, gt_states, gt_actions, gt_mask, group=None, warmup=3):
+        self.policy, self.opt, self.group = policy, optimizer, group
+        self.static = [t.detach().clone() for t in (x0, gt_states, gt_actions, gt_mask)]
+        self.step_in_graph = group is None and all(g.get("capturable", False) for g in optimizer.param_groups)
+        self._flags = []
+        check = al_mpc.CHECK_CHOLESKY
+        al_mpc.CHECK_CHOLESKY = False
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    optimizer.zero_grad(set_to_none=True)
+                    self._body()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.graph):
+                self.out = self._body()
+                self._flags = list(getattr(policy.tracking_mpc.ctrl, "fail_log", []))
+        finally:
+            al_mpc.CHECK_CHOLESKY = check
+
+    def _body(self):
+        ctrl = self.policy.tracking_mpc.ctrl
+        if hasattr(ctrl, "fail_log"):
+            ctrl.fail_log = []
+        trajs, dyn_res = self.policy(*self.static)
+        loss, loss_end = compute_loss_deqmpc(self.policy, self.static[1], self.static[2], self.static[3], trajs)
+        loss.backward()
+        if self.step_in_graph:
+            self.opt.step()
+        return loss.detach(), loss_end.detach(), dyn_res
+
+    def __call__(self, x0, gt_states, gt_actions, gt_mask):
+        for dst, src in zip(self.static, (x0, gt_states, gt_actions, gt_mask)):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        self.graph.replay()
+        if not self.step_in_graph:
+            allreduce_gradients(self.policy.model, self.group)
+            self.opt.step()
+        return self.out
+
+    def failed(self):
+        return any(bool(f.any()) for f in self._flags)

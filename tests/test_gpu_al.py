@@ -562,3 +562,61 @@ def test_al_mpc_cholesky_failure_takes_the_lu_path(name, robot):
     dQ, dq = aso.backward(o["L"], o["xu"], gxu, chol_fail=True)
     np.testing.assert_allclose(C.grad.diagonal(dim1=-2, dim2=-1).cpu().numpy()[ok], dQ[ok], rtol=1e-3, atol=1e-5)
     np.testing.assert_allclose(c.grad.cpu().numpy()[ok], dq[ok], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("robot,T,B", [("cartpole2l", 5, 128), ("rexquadrotor", 6, 37)])
+def test_al_graphed_mpc_bitwise_equal_to_eager(robot, T, B):
+    """AL_mpc.GraphedMPC (a cold AL_mpc.MPC call -- reinitialize + forward -- and its backward replayed as hipGraphs)
+    against the eager call on the same inputs: x, u and the gradients wrt C and c bit for bit, on the captured batch and
+    on a second batch copied into the static inputs; and the one-call solve (dqp_al_mpc_solve) against round 2's host loop
+    around the Newton solves (ONE_CALL_SOLVE = False): identical kernels in the same order, bit for bit as well."""
+    from diff_qp_mpc_amd import AL_mpc, al_utils
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    dyn = DeviceDynamics(robot)
+    nx, nu = dyn.n_state, dyn.n_ctrl
+    rng = np.random.default_rng(3)
+    lo, hi = (dev(np.full(nu, 11.5)), dev(np.full(nu, 18.3))) if robot == "rexquadrotor" else (dev(np.full(nu, -250.0)), dev(np.full(nu, 250.0)))
+    Qd = dev(np.concatenate([np.ones(nx), 1e-3 * np.ones(nu)])).repeat(B, T, 1)
+
+    def batch(seed):
+        r = np.random.default_rng(seed)
+        x0 = dev(r.uniform(-0.5, 0.5, (B, nx)))
+        x_ref = x0[:, None, :] * torch.linspace(1.0, 0.0, T, dtype=torch.float64, device="cuda")[None, :, None]
+        u_ref = ((lo + hi) / 2).repeat(B, T, 1)
+        C = torch.diag_embed(Qd).requires_grad_()
+        c = (-(Qd * torch.cat([x_ref, u_ref], -1))).clone().requires_grad_()
+        return x0, x_ref, u_ref, C, c
+
+    def make():
+        return AL_mpc.MPC(nx, nu, T, u_lower=lo, u_upper=hi, n_batch=B, verbose=0, solver_type="dense", dtype=torch.float64,
+                          eps=1e-5, exit_unconverged=False, backprop=False)
+
+    def eager(x0, x_ref, u_ref, C, c):
+        ctrl = make()
+        ctrl.reinitialize(x0, torch.ones(B, T, 1, device="cuda"))
+        ctrl.x_init, ctrl.u_init = x_ref, u_ref
+        x, u = ctrl(x0, al_utils.QuadCost(C, c), dyn, dyn.jac)
+        gC, gc = torch.autograd.grad(x.double().sum() + 2.0 * u.double().sum(), (C, c))
+        return x.detach(), u.detach(), gC, gc
+
+    x0, x_ref, u_ref, C, c = batch(0)
+    want = eager(x0, x_ref, u_ref, C, c)
+    AL_mpc.ONE_CALL_SOLVE = False
+    try:
+        old = eager(x0, x_ref, u_ref, C, c)
+    finally:
+        AL_mpc.ONE_CALL_SOLVE = True
+    for a, b in zip(old, want):
+        assert torch.equal(a, b)
+    ctrl = make()
+    ctrl.mask = torch.ones(B, T, 1, device="cuda")
+    g = AL_mpc.GraphedMPC(ctrl, (x0, C, c), dyn, x_init=x_ref, u_init=u_ref)
+    for seed in (0, 1):
+        x0b, x_refb, u_refb, Cb, cb = batch(seed)
+        g.x_init.copy_(x_refb); g.u_init.copy_(u_refb)         # the static initial guess of the captured call
+        x, u = g(x0b, Cb, cb)
+        gC, gc = torch.autograd.grad(x.double().sum() + 2.0 * u.double().sum(), (Cb, cb))
+        wb = eager(x0b, x_refb, u_refb, Cb, cb)
+        for a, b in zip((x, u, gC, gc), wb):
+            assert torch.equal(a, b)
+    assert not g.failed()
