@@ -31,7 +31,7 @@ R16N_SIZES = [s for s in R16_SIZES if s[2] > 0] + [
 ]
 
 PLAIN_SOURCES = ["dqp_pdipm.hip", "dqp_mpc.hip", "dqp_al.hip", "dqp_term.hip", "dqp_dyn.hip", "dqp_al_banded.hip",
-                 "dqp_ric.hip", "dqp_trace.hip"]
+                 "dqp_ric.hip", "dqp_trace.hip", "dqp_big.hip"]
 SOURCES = PLAIN_SOURCES + ["dqp_r16.hip", "dqp_r16n.hip", "dqp_dispatch.hip"]
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-MD",
          "-mllvm", "-pragma-unroll-threshold=10000000", "-mllvm", "-unroll-threshold=10000000"]

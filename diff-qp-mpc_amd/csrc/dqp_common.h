@@ -116,6 +116,11 @@ int ric_forward_stepped(const KParams &P, void *stream);   // iterations [P.itBe
 int ric_backward(const KParams &P, void *stream);
 int ric_snapshot_doubles(int n_state, int n_ctrl, int T);   // iterate snapshot of the batch rule's finish pass
 int ric_finish(const KParams &P, void *stream);
+// dense QPs above DQP_MAX_DIM (dqp_big.hip): one QP per workgroup, matrices in the workspace, MFMA tiles
+long long big_workspace_doubles(int N, int M, int E);
+bool big_fits(int N, int M, int E);         // the solver's vectors fit the LDS of a CU
+int big_forward(const KParams &P, void *stream);
+int big_backward(const KParams &P, void *stream);
 // backward restarted from the context r16n_forward left in P.workspace (DQP_FLAG_BACKWARD_CTX)
 int r16n_backward(const KParams &P, void *stream);
 

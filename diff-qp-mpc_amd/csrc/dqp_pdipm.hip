@@ -674,6 +674,8 @@ __global__ __launch_bounds__(WAVE) void qp_backward_kernel(KParams P)
     if (lane == 0 && P.info) { P.info[2 * qp] = status; P.info[2 * qp + 1] = 0; }
 }
 
+static inline bool is_big(const KParams &P) { return P.N > DQP_MAX_DIM || P.M > DQP_MAX_DIM || P.E > DQP_MAX_DIM; }
+
 void fill_opts(const dqp_opts *o, KParams &P)
 {
     P.eps = (o ? o->eps : 1e-12) * 0.1;
@@ -693,8 +695,17 @@ int fill_params(const dqp_dims *d, const dqp_opts *o, KParams &P, size_t &lds_by
 #endif
     if (!d) return DQP_ERR_BAD_ARG;
     if (d->nbatch < 0 || d->nz <= 0 || d->nineq <= 0 || d->neq < 0) return DQP_ERR_BAD_ARG;
-    if (d->nz > DQP_MAX_DIM || d->nineq > DQP_MAX_DIM || d->neq > DQP_MAX_DIM) return DQP_ERR_TOO_LARGE;
+    if (d->nz > DQP_MAX_DIM_LARGE || d->nineq > DQP_MAX_DIM_LARGE || d->neq > DQP_MAX_DIM_LARGE) return DQP_ERR_TOO_LARGE;
     P.B = d->nbatch; P.N = d->nz; P.M = d->nineq; P.E = d->neq;
+    if (is_big(P)) {        // one QP per workgroup, matrices in the caller's workspace (dqp_big.hip)
+        if (!big_fits(P.N, P.M, P.E)) return DQP_ERR_TOO_LARGE;
+        if (o && o->dyn_id) return DQP_ERR_BAD_ARG;
+        P.sQ = d->stride_Q; P.sp = d->stride_p; P.sG = d->stride_G;
+        P.sh = d->stride_h; P.sA = d->stride_A; P.sb = d->stride_b;
+        fill_opts(o, P);
+        lds_bytes = 0;
+        return DQP_OK;
+    }
     P.ldz = d->nz | 1; P.ldm = d->nineq | 1; P.lde = d->neq | 1;
     P.ldt = P.ldz > P.ldm ? P.ldz : P.ldm;
     P.sQ = d->stride_Q; P.sp = d->stride_p; P.sG = d->stride_G;
@@ -778,6 +789,10 @@ __attribute__((visibility("default"))) const char *dqp_error_string(int code)
 __attribute__((visibility("default"))) size_t dqp_workspace_bytes(const dqp_dims *d)
 {
     if (!d || d->nbatch <= 0) return 0;
+    if (d->nz > DQP_MAX_DIM || d->nineq > DQP_MAX_DIM || d->neq > DQP_MAX_DIM) {        // required at these sizes
+        if (d->nz > DQP_MAX_DIM_LARGE || d->nineq > DQP_MAX_DIM_LARGE || d->neq > DQP_MAX_DIM_LARGE) return 0;
+        return (size_t)d->nbatch * (size_t)dqp::big_workspace_doubles(d->nz, d->nineq, d->neq) * sizeof(double);
+    }
     return (size_t)d->nbatch * (size_t)dqp::r16n_workspace_doubles(d->nz, d->nineq, d->neq) * sizeof(double);
 }
 
@@ -817,7 +832,7 @@ dqp_qp_forward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, cons
     if (!termination || P.maxIter < 1 || P.maxIter > 64) return DQP_ERR_BAD_ARG;
     P.eps = opts ? opts->eps : 1e-12;            // the batch rule uses the reference's eps itself
     // null-space kernels keep their improving iterates: pass 2 is then an epilogue, not a re-solve
-    const bool nullspace = workspace && !(P.flags & (DQP_FLAG_GENERIC_ONLY | DQP_FLAG_NO_NULLSPACE)) && !P.dynId;
+    const bool nullspace = workspace && !(P.flags & (DQP_FLAG_GENERIC_ONLY | DQP_FLAG_NO_NULLSPACE)) && !P.dynId && !is_big(P);
     term_bind_pass1(P, termination, nullspace ? r16n_snapshot_doubles(P.N, P.M, P.E) : 0);
     if ((rc = forward_once(P, lds, workspace, stream)) != DQP_OK) return rc;
     if (P.flags & DQP_FLAG_HISTORY_ONLY) return DQP_OK;
@@ -861,7 +876,7 @@ dqp_qp_forward_finish(const dqp_dims *dims, const dqp_opts *opts, const double *
     P.zhat = zhat; P.lam = lam; P.nu = nu; P.slack = slack;
     P.info = info; P.best_resid = best_resid;
     P.eps = opts ? opts->eps : 1e-12;
-    const bool nullspace = workspace && !(P.flags & (DQP_FLAG_GENERIC_ONLY | DQP_FLAG_NO_NULLSPACE)) && !P.dynId;
+    const bool nullspace = workspace && !(P.flags & (DQP_FLAG_GENERIC_ONLY | DQP_FLAG_NO_NULLSPACE)) && !P.dynId && !is_big(P);
     term_bind_pass1(P, termination, nullspace ? r16n_snapshot_doubles(P.N, P.M, P.E) : 0);    // (snapshot pointer)
     if ((rc = term_decide_global(P, termination, (const unsigned long long *)masks, stream)) != DQP_OK) return rc;
     term_bind_pass2(P, termination);
@@ -871,6 +886,7 @@ dqp_qp_forward_finish(const dqp_dims *dims, const dqp_opts *opts, const double *
 static int forward_once(const KParams &P, size_t lds, void *workspace, void *stream)
 {
     int rc;
+    if (is_big(P)) return workspace ? big_forward(P, stream) : DQP_ERR_BAD_ARG;
     if (!(P.flags & DQP_FLAG_GENERIC_ONLY) && !P.dynId) {
         // DPP-row kernels for the instantiated sizes: the null-space form when the caller gave
         // it its workspace (and did not opt out), else the form that keeps the equality rows.
@@ -1099,6 +1115,7 @@ dqp_qp_backward(const dqp_dims *dims, const dqp_opts *opts, const double *Q, con
     P.dQ = dQ; P.dp = dp; P.dG = dG; P.dh = dh; P.dA = dA; P.db = db;
     P.info = info;
     P.workspace = (double *)workspace;
+    if (is_big(P)) return workspace ? big_backward(P, stream) : DQP_ERR_BAD_ARG;
     if (!(P.flags & DQP_FLAG_GENERIC_ONLY)) {
         // Backward is ONE solve, always in the Schur-complement form (T = Gz Gz^T + D^-1 keeps
         // dlam accurate for strongly active constraints, d ~ 1e8 after the reference's clamps).

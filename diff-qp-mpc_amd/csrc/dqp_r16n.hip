@@ -46,6 +46,12 @@ template <int N_, int M_, int E_> struct Cfg {
     static constexpr int SN = slots(N_), SM = slots(M_), SR = slots(N_ - E_);
     static constexpr int SE = E_ > 0 ? slots(E_) : 1, EC = E_ > 0 ? E_ : 1;
     static constexpr bool PARK = slots(N_) >= 3;        // W, U leave the registers between setup and epilogue
+#ifndef DQP_R16N_PARK_WU
+#define DQP_R16N_PARK_WU 1
+#endif
+    // the same for the two-slot sizes, without the split passes: W and U are dead between setup and epilogue and are
+    // in the workspace anyway (the backward context); 1 drops them from the register file during the iteration
+    static constexpr bool PARKWU = PARK || DQP_R16N_PARK_WU;
 #ifndef DQP_R16N_PIN_ALL
 #define DQP_R16N_PIN_ALL 1
 #endif
@@ -746,10 +752,10 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
             if (k < E) { ws[C::wXy + k] = st.xy[s]; ws[C::wPy + k] = st.py[s]; ws[C::wW1 + k] = st.w1[s]; }
         }
     }
-    if (C::PARK && E > 0) {
+    if (C::PARKWU && E > 0) {
         // three register slots per N-space matrix: W and U leave the register file here (phase G
         // needs the room for Lq Qf) and come back for the epilogue
-        park_GU<C>(P.workspace + qp * (long long)C::wsQP, st, r);
+        if (C::PARK || !C::EARLY) park_GU<C>(P.workspace + qp * (long long)C::wsQP, st, r);
 #pragma unroll
         for (int s = 0; s < SM; ++s)
 #pragma unroll
@@ -831,7 +837,7 @@ __device__ __forceinline__ void setup(const KParams &P, long long qp, int r, dou
             double *ws = P.workspace + qp * (long long)C::wsQP;
             for (int e = r; e < C::tailsz; e += 16) ws[C::wTl + e] = lds[C::oTl + e];
             for (int e = r; e < tri(N); e += 16) ws[C::wLq + e] = lds[C::oLq + e];
-            if (!C::PARK) park_GU<C>(ws, st, r);
+            if (!C::PARKWU) park_GU<C>(ws, st, r);
 #pragma unroll
             for (int s = 0; s < SN; ++s)
                 if (r + 16 * s < N) ws[C::wRdq + r + 16 * s] = st.rdq[s];
@@ -927,7 +933,7 @@ __device__ __forceinline__ void epilogue(const KParams &P, long long qp, int r, 
 #pragma unroll
     for (int s = 0; s < SE; ++s) yv[s] = 0.0;
     if (E > 0) {
-        if (C::PARK) unpark_WU<C>(P.workspace + qp * (long long)C::wsQP, st, r);
+        if (C::PARKWU) unpark_WU<C>(P.workspace + qp * (long long)C::wsQP, st, r);
         shift_up<C>(st.xy, xh, r);
         apply_Qf<C>(lds, st.tau, xh, r);
         double wz[SE];

@@ -188,8 +188,9 @@ def _forward_impl(Q_, p_, G_, h_, A_, b_, eps, maxIter, notImprovedLim, terminat
         _lib.check(rc, "dqp_qp_forward")
     # the workspace now holds the factorisation context backward can restart from (include/dqp.h)
     # (only the null-space kernels leave one: not the forced families, not the true-dynamics path)
+    big = max(nz, nineq, neq) > _lib.DQP_MAX_DIM         # one QP per workgroup, matrices in the workspace (dqp_big.hip)
     ctx_ws = ws if (ws is not None and dyn is None and
-                    not (FORCE_FLAGS & (_lib.DQP_FLAG_NO_NULLSPACE | _lib.DQP_FLAG_GENERIC_ONLY))) else None
+                    (big or not (FORCE_FLAGS & (_lib.DQP_FLAG_NO_NULLSPACE | _lib.DQP_FLAG_GENERIC_ONLY)))) else None
     return zhat, lam, nu, slack, info, resid, (Q, G, A, dims, ctx_ws)
 
 
@@ -206,7 +207,8 @@ def _backward_impl(saved, zhat, lam, nu, slack, dl_dzhat, need, flags):
     dh = torch.empty(nBatch, nineq, **kw) if need[3] else None
     dA = torch.empty(nBatch, neq, nz, **kw) if (need[4] and neq > 0) else None
     db = torch.empty(nBatch, neq, **kw) if (need[5] and neq > 0) else None
-    if ctx_ws is not None and not (FORCE_FLAGS & (_lib.DQP_FLAG_NO_NULLSPACE | _lib.DQP_FLAG_GENERIC_ONLY)):
+    big = max(nz, nineq, neq) > _lib.DQP_MAX_DIM
+    if ctx_ws is not None and (big or not (FORCE_FLAGS & (_lib.DQP_FLAG_NO_NULLSPACE | _lib.DQP_FLAG_GENERIC_ONLY))):
         flags |= _lib.DQP_FLAG_BACKWARD_CTX
     opts = _lib.dqp_opts(0.0, 0.0, 0, 0, flags | FORCE_FLAGS, 0)
     with torch.cuda.device(dev):

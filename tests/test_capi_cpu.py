@@ -40,7 +40,7 @@ def test_version_and_error_strings(lib):
 def test_argument_validation_without_gpu(lib):
     from diff_qp_mpc_amd import _lib
     z = ctypes.c_void_p(0)
-    d = _lib.dqp_dims(4, 65, 3, 0, 0, 0, 0, 0, 0, 0)
+    d = _lib.dqp_dims(4, 513, 3, 0, 0, 0, 0, 0, 0, 0)          # DQP_MAX_DIM_LARGE = 512
     assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 15)) == -2
     d = _lib.dqp_dims(4, 5, 3, 2, 0, 0, 0, 0, 0, 0)
     assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 15)) == -1   # null pointers

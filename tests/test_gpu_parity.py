@@ -376,7 +376,7 @@ def test_empty_batch_and_bad_dims(dqp):
     import ctypes
     from diff_qp_mpc_amd import _lib
     lib = _lib.load()
-    d = _lib.dqp_dims(4, 65, 3, 0, 0, 0, 0, 0, 0, 0)
+    d = _lib.dqp_dims(4, 513, 3, 0, 0, 0, 0, 0, 0, 0)          # DQP_MAX_DIM_LARGE = 512
     z = ctypes.c_void_p(0)
     assert lib.dqp_qp_forward(ctypes.byref(d), None, *([z] * 15)) == -2      # too large
     d = _lib.dqp_dims(4, 5, 0, 0, 0, 0, 0, 0, 0, 0)

@@ -13,10 +13,14 @@ from diff_qp_mpc_amd import _build
 
 def build(source, specs):
     jobs = list(_build._jobs())
-    target = [(o, c) for o, c in jobs if os.path.basename(o) == source.replace(".hip", ".o")]
+    # SOURCE is a .hip file with one object, or the object itself for the per-size translation units
+    # (dqp_r16n_30_30_15.o: the metric-size null-space forward, compiled from dqp_r16n.hip)
+    want = source if source.endswith(".o") else source.replace(".hip", ".o")
+    target = [(o, c) for o, c in jobs if os.path.basename(o) == want]
     assert len(target) == 1, "no single object for " + source
     obj, cmd = target[0]
-    src_path = os.path.join(_build.CSRC, source)
+    src_path = cmd[cmd.index("-c") + 1]
+    source = os.path.basename(src_path)
     procs = []
     for spec in specs:
         name, rest = spec.split("=", 1)
