@@ -44,8 +44,9 @@ def sl1qpify(Q, p, G, h, A, b, mu, reg=1e-6):
 
 
 def SL1QPFunction(mu=10.0, reg=1e-6, **solver_kw):
-    """Callable (Q, p, G, h, A, b) -> z of the l1-penalised problem, solved by DenseQPFunction on the
-    MI355X kernels (the extended sizes must fit them: nz + 2 neq + nineq <= 64)."""
+    """Callable (Q, p, G, h, A, b) -> z of the l1-penalised problem, solved by DenseQPFunction on the MI355X kernels:
+    the one-wavefront kernels up to 64 extended variables, the blocked dense kernels (csrc/dqp_big.hip) above -- MPC
+    shapes: 90 extended variables at n 3 m 3 T 5, 120 at the pendulum's T 10 (limit: 512, include/dqp.h)."""
     solve = DenseQPFunction(**solver_kw)
 
     def apply(Q, p, G, h, A, b):

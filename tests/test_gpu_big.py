@@ -129,3 +129,67 @@ def test_prof_linear_500():
     og = oracle.qp_backward(Q[:2], G[:2], A[:2], o["zhat"], o["lam"], o["nu"], o["slack"], np.ones((2, nz)))
     for k, t in zip("QpGh", ins[:4]):
         np.testing.assert_allclose(t.grad[:2].cpu().numpy()[cm], og["d" + k][cm], err_msg="d" + k, **GT)
+
+
+@pytest.mark.parametrize("n,m,T", [(3, 3, 5), (3, 1, 10)])
+def test_sl1qp_at_mpc_shapes(n, m, T):
+    """The l1-slack reformulation (sl1qp_mpc.py:703-752, general sizes: sl1qp.sl1qpify) of an MPC-structured QP at the
+    BASELINE metric shape (n 3, m 3, T 5: 30 + 2 x 15 + 30 = 90 extended variables) and at config 2's shape (n 3, m 1,
+    T 10: 120), on the blocked dense kernels: z against the CPU oracle's DenseQPFunction restatement on the same extended
+    QP (rtol 1e-6 / atol 1e-8), and -- exact-penalty regime, mu above the multipliers -- against the hard QP's solution
+    (rtol 1e-3 / atol 1e-4: the slack block of Q is reg I = 1e-6 I).  Gradients flow to all six inputs."""
+    import diff_qp_mpc_amd as dqp
+    from diff_qp_mpc_amd import sl1qp
+    from families import family_mpc
+    B = 6
+    Q, p, G, h, A, b = [dev(a) for a in family_mpc(2, B, n, m, T)]
+    nz, neq, nineq = T * (n + m), T * n, 2 * T * m
+    mu = 200.0
+    ext = sl1qp.sl1qpify(Q, p, G, h, A, b, mu=mu)
+    assert ext[0].shape[-1] == nz + 2 * neq + nineq and ext[0].shape[-1] > 64
+    z_soft = sl1qp.SL1QPFunction(mu=mu, verbose=-1)(Q, p, G, h, A, b)
+    o = oracle.dense_forward(*[t.detach().cpu().numpy() for t in ext])
+    np.testing.assert_allclose(z_soft.detach().cpu().numpy(), o["zhat"][:, :nz], **ZT)
+    z_hard = dqp.DenseQPFunction(verbose=-1)(*[t.detach() for t in (Q, p, G, h, A, b)])
+    np.testing.assert_allclose(z_soft.detach().cpu().numpy(), z_hard.cpu().numpy(), rtol=1e-3, atol=1e-4)
+    z_soft.sum().backward()
+    assert all(t.grad is not None and bool(torch.isfinite(t.grad).all()) for t in (Q, p, G, h, A, b))
+
+
+def test_sl1qp_mpc_clone_matches_qp_wrapper_in_the_exact_penalty_regime():
+    """sl1qp_mpc.MPC (the reference's clone cannot run: unconditional ipdb.set_trace(), sl1qp_mpc.py:326 -- parity
+    unpinned) on LinDx data, n 3 m 3 T 5: with mu above the multipliers the l1 penalty is exact, so trajectories and
+    gradients agree with qp_wrapper.MPC on the same problem (x, u rtol 1e-3 / atol 1e-4; gradients rtol 2e-2 / atol 1e-4)
+    and the slacks vanish; with a small mu and bounds the dynamics cannot meet, the problem stays solvable (finite x, u,
+    non-zero slack)."""
+    from diff_qp_mpc_amd import qp_wrapper, sl1qp_mpc
+    n, m, T, B = 3, 3, 5, 8
+    gen = torch.Generator().manual_seed(42)
+    Ad = torch.eye(n, dtype=torch.float64) + 0.2 * torch.randn(n, n, generator=gen, dtype=torch.float64)
+    Bd = torch.randn(n, m, generator=gen, dtype=torch.float64)
+    c0 = torch.randn(T, B, n + m, generator=gen, dtype=torch.float64)
+    x0 = torch.randn(B, n, generator=gen, dtype=torch.float64).cuda()
+    F = torch.cat([Ad, Bd], 1).repeat(T - 1, B, 1, 1).cuda()
+    f = torch.zeros(T - 1, B, n, dtype=torch.float64).cuda()
+    one = torch.ones(m, dtype=torch.float64).cuda()
+    res = {}
+    for name, make in (("hard", lambda: qp_wrapper.MPC(n, m, T, u_lower=-one, u_upper=one, n_batch=B, verbose=-1, single_qp_solve=True)),
+                       ("soft", lambda: sl1qp_mpc.MPC(n, m, T, u_lower=-one, u_upper=one, n_batch=B, verbose=-1, single_qp_solve=True, mu=500.0))):
+        C = torch.eye(n + m, dtype=torch.float64).repeat(T, B, 1, 1).cuda().requires_grad_()
+        c = c0.clone().cuda().requires_grad_()
+        ctrl = make()
+        args = (x0, qp_wrapper.QuadCost(C, c), qp_wrapper.LinDx(F, f))
+        x, u = ctrl(*args) if name == "soft" else ctrl(*args, None)
+        (x.sum() + 2.0 * u.sum()).backward()
+        res[name] = (x.detach().cpu().numpy(), u.detach().cpu().numpy(), C.grad.cpu().numpy(), c.grad.cpu().numpy(), ctrl)
+    for a, b_, tol in zip(res["soft"][:4], res["hard"][:4], (dict(rtol=1e-3, atol=1e-4),) * 2 + (dict(rtol=2e-2, atol=1e-4),) * 2):
+        np.testing.assert_allclose(a, b_, **tol)
+    v, w, t = res["soft"][4].slacks
+    assert float(v.abs().max()) < 1e-5 and float(w.abs().max()) < 1e-5 and float(t.abs().max()) < 1e-5
+    # softened: tiny bounds, the initial-state row still has to hold -> violations are bought at mu per unit
+    tiny = 1e-3 * one
+    ctrl = sl1qp_mpc.MPC(n, m, T, u_lower=-tiny, u_upper=tiny, n_batch=B, verbose=-1, single_qp_solve=True, mu=0.05)
+    x, u = ctrl(x0, qp_wrapper.QuadCost(torch.eye(n + m, dtype=torch.float64).repeat(T, B, 1, 1).cuda(), c0.cuda()),
+                qp_wrapper.LinDx(F, f))
+    assert bool(torch.isfinite(x).all()) and bool(torch.isfinite(u).all())
+    assert float(sum(s.abs().sum() for s in ctrl.slacks)) > 1e-3
