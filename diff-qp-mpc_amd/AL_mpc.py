@@ -26,10 +26,14 @@ ONE_CALL_SOLVE = True
 # (False: never look -- needed to capture a call in a hipGraph; a failed factorisation then leaves its
 # problem at the last accepted iterate)
 CHECK_CHOLESKY = True
-# caller-supplied dynamics modules: the block-tridiagonal step on the module's own Jacobians once the QP no longer
-# fits the dense Newton step (nz > 128); 0 would use it at every size
+# caller-supplied dynamics modules: the block-tridiagonal step on the module's own Jacobians (dqp_al_banded_newton_step_jac)
+# at every size it exists for (n_state + n_ctrl <= 16, compiled pairs).  Round 3 retired the dense Newton step
+# (dqp_al_newton_step: nz <= 128, 14 % of the fp64 peak with ~48 % useful FMAs in its cyclic LDL^T) as the default of
+# this path: the banded step is faster at every size measured (tools/bench_al_user.py: nz 60: 9.7 -> 7.4 ms per call,
+# nz 120: 19.8 -> 9.7 ms, same iterates to 1e-10) -- the dense kernel stays for shapes without a banded instantiation
+# and behind this threshold (set it to 128 for round 2's behaviour)
 BANDED_USER_DYNAMICS = True
-BANDED_USER_DYNAMICS_FROM_NZ = 128
+BANDED_USER_DYNAMICS_FROM_NZ = 0
 
 
 def _detach(t):

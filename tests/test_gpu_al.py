@@ -216,8 +216,19 @@ def test_merit_kernel(B, T, k, n, m):
         np.testing.assert_allclose(alt.cpu().numpy().reshape(-1, B), np.stack(want), rtol=1e-12, atol=1e-10)
 
 
+@pytest.fixture(params=[0, 128], ids=["banded-jac", "dense-newton"])
+def user_dynamics_path(request):
+    """caller-supplied dynamics modules: the block-tridiagonal step on the module's Jacobians (default, every size) or the
+    dense Newton step (dqp_al_assemble + dqp_al_newton_step, round 2's default below nz = 128)"""
+    from diff_qp_mpc_amd import AL_mpc
+    old = AL_mpc.BANDED_USER_DYNAMICS_FROM_NZ
+    AL_mpc.BANDED_USER_DYNAMICS_FROM_NZ = request.param
+    yield request.param
+    AL_mpc.BANDED_USER_DYNAMICS_FROM_NZ = old
+
+
 @pytest.mark.parametrize("name", AL_CASES)
-def test_al_mpc_two_calls_vs_reference(name):
+def test_al_mpc_two_calls_vs_reference(name, user_dynamics_path):
     from diff_qp_mpc_amd import AL_mpc, al_utils
     g = load(name)
     B, T = g["in_Qd"].shape[:2]

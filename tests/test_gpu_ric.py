@@ -125,17 +125,20 @@ def test_stagewise_vs_cpu_oracle(n, m, T, B):
         np.testing.assert_allclose(a, want, err_msg=k, **GT)
 
 
-def test_config4_size_kkt_properties():
-    """n 12, m 4, T 30 (nz 480, nineq 240, neq 360), B = 256: stationarity, primal feasibility,
-    complementarity and sign conditions of the returned (tau, lam, nu, slack) on the original data."""
+@pytest.mark.parametrize("B,batch_rule", [(256, False), (8192, True)])
+def test_config4_size_kkt_properties(B, batch_rule):
+    """n 12, m 4, T 30 (nz 480, nineq 240, neq 360) at B = 256 and at BASELINE config 4's own batch, B = 8192 (771 MB of
+    workspace, the kernels' 32-bit offset guards; there under the batch rule, with its 1.4 GB termination buffer):
+    stationarity, primal feasibility, complementarity and sign conditions of the returned (tau, lam, nu, slack) on the
+    original data."""
     from diff_qp_mpc_amd import _lib
-    n, m, T, B = 12, 4, 30, 256
+    n, m, T = 12, 4, 30
     nt = n + m
     C, c, F, f, x0, lo, hi = problem(n, m, T, B, seed=3, spread=0.05)      # 30 steps: keep the rollout bounded
     lib = _lib.load()
     dims = _lib.dqp_mpc_dims(B, n, m, T, 1, 0)
     assert lib.dqp_mpc_qp_supported(ctypes.byref(dims)) == 1
-    opts = _lib.dqp_opts(1e-12, 1e-10, 20, 3, 0, 0)
+    opts = _lib.dqp_opts(1e-12, 1e-10, 20, 3, _lib.DQP_FLAG_BATCH_TERMINATION if batch_rule else 0, 0)
     t = [dev(a) for a in (C, c, F, f, x0, lo, hi)]
     kw = dict(dtype=torch.float64, device="cuda")
     tau = torch.empty(B, T, nt, **kw); lam = torch.empty(B, 2 * T * m, **kw); slack = torch.empty(B, 2 * T * m, **kw)
@@ -143,8 +146,10 @@ def test_config4_size_kkt_properties():
     ws = torch.empty(int(lib.dqp_mpc_qp_workspace_bytes(ctypes.byref(dims))) // 8, **kw)
     P = lambda x: ctypes.c_void_p(x.data_ptr())
     resid = torch.empty(B, **kw)
+    tb = int(lib.dqp_mpc_qp_termination_bytes(ctypes.byref(dims), ctypes.byref(opts)))
+    term = torch.empty(tb // 8 + 1, **kw) if tb else None
     rc = lib.dqp_mpc_qp_forward(ctypes.byref(dims), ctypes.byref(opts), *[P(x) for x in t], P(tau), P(lam), P(nu),
-                                P(slack), P(info), P(resid), P(ws), None, None)
+                                P(slack), P(info), P(resid), P(ws), P(term) if tb else None, None)
     assert rc == 0
     torch.cuda.synchronize()
     assert int(info[:, 0].abs().max()) == 0
