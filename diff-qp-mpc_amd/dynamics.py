@@ -139,6 +139,38 @@ class DeviceDynamics(torch.nn.Module):
         return blocks
 
 
+def recognise(module, n_state, n_ctrl, dt=None, device="cuda", samples=16, tol=1e-9):
+    """Is `module` (a caller's torch dynamics, e.g. the reference's env.dynamics: deqmpc/envs.py PendulumDynamics,
+    deqmpc/my_envs/dynamics.py Dynamics, rex_quadrotor.py) one of the registered device models?  Every registered
+    model with these sizes is evaluated next to the module at `samples` seeded random points (step `dt`, default: the
+    module's own `.dt` attribute, else the model's default) and the first one that reproduces it to `tol` (relative to
+    1 + |x_next|) is returned as a DeviceDynamics -- so that a maintainer switching over keeps passing the env's module and
+    still gets the on-chip solver paths.  Returns None when nothing matches (the module then takes the general paths:
+    its own Jacobians into the block-tridiagonal Newton step, its residual into the caller-stepped PDIPM).  Nothing is
+    substituted on a guess: the match is numerical, on the module the caller actually passed."""
+    if isinstance(module, DeviceDynamics):
+        return module
+    gen = torch.Generator().manual_seed(0)
+    x = (torch.rand(samples, n_state, generator=gen, dtype=torch.float64) * 2 - 1).to(device)
+    u = (torch.rand(samples, n_ctrl, generator=gen, dtype=torch.float64) * 2 - 1).to(device)
+    try:
+        with torch.no_grad():
+            ref = module(x, u)
+    except Exception:
+        return None
+    if not torch.is_tensor(ref) or ref.shape != x.shape:
+        return None
+    step = dt if dt is not None else getattr(module, "dt", None)
+    for name in NAMES:
+        cand = DeviceDynamics(name, dt=float(step) if step is not None else None)
+        if (cand.n_state, cand.n_ctrl) != (n_state, n_ctrl):
+            continue
+        got = cand(x, u)
+        if bool(((got - ref.double()).abs() <= tol * (1.0 + ref.double().abs())).all()):
+            return cand
+    return None
+
+
 class DynamicsResidual:
     """The `dyn_res` closure qp_wrapper.MPC hands to the QP solver (qp_wrapper.py:309,326-345):
     z (B, T (n+m)) -> [f(x_t,u_t) - x_{t+1}]_{t<T-1}, x_0 - x0 [, x_{T-1} (goal rows)], with f a

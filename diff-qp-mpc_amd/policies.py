@@ -19,8 +19,13 @@ import torch
 import torch.nn as nn
 
 from . import AL_mpc as al_mpc
+from .dynamics import DeviceDynamics, recognise
 from . import al_utils
 from . import qp_wrapper as ip_mpc
+
+
+# Tracking_MPC: look at the env's dynamics module and use the registered device model when it is one (dynamics.recognise)
+RECOGNISE_ENV_DYNAMICS = True
 
 
 class DEQLayer(nn.Module):
@@ -70,7 +75,14 @@ class Tracking_MPC(nn.Module):
         super().__init__()
         self.args = args
         self.nu, self.nx, self.nq, self.dt, self.T = env.nu, env.nx, getattr(env, "nq", args.nq), env.dt, args.T
-        self.dyn, self.dyn_jac = env.dynamics, env.dynamics_derivatives
+        dyn, dyn_jac = env.dynamics, env.dynamics_derivatives
+        if RECOGNISE_ENV_DYNAMICS and not isinstance(dyn, DeviceDynamics):
+            # the reference passes its env's torch module (policies.py:571-572): if it IS one of the registered device
+            # models (checked numerically on the module itself, dynamics.recognise), the solver calls stay on chip
+            known = recognise(dyn, env.nx, env.nu, dt=getattr(env, "dt", None), device=args.device)
+            if known is not None:
+                dyn, dyn_jac = known, known.jac
+        self.dyn, self.dyn_jac = dyn, dyn_jac
         self.device = args.device
         self.dtype = torch.float64 if args.dtype == "double" else torch.float32
         self.u_upper = torch.as_tensor(env.action_space.high).to(self.device)

@@ -116,3 +116,59 @@ def test_bad_arguments(dynmod):
         dynmod.DeviceDynamics("cartpole1l")(torch.zeros(2, 4, dtype=torch.float64), torch.zeros(2, 1, dtype=torch.float64))
     with pytest.raises(ValueError):
         dynmod.DeviceDynamics("acrobot")
+
+
+def test_recognise_a_callers_module():
+    """dynamics.recognise: a caller's torch module that IS a registered model (here: the pendulum of deqmpc/envs.py
+    restated in torch, and a registered model behind an opaque wrapper) is matched numerically and returned as the
+    device model; a different map (another step size, a perturbed model) is not."""
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics, recognise
+    from test_gpu_al import Pendulum
+
+    m = recognise(Pendulum(), 2, 1)
+    assert isinstance(m, DeviceDynamics) and m.name == "pendulum_euler" and m.dt == 0.05
+
+    class Wrap(torch.nn.Module):
+        def __init__(self, d, scale=1.0):
+            super().__init__()
+            self.d, self.dt, self.scale = d, d.dt, scale
+
+        def forward(self, x, u):
+            return self.d(x, u * self.scale)
+
+    for name in ("cartpole1l", "cartpole2l", "rexquadrotor", "pendulum_dx"):
+        d = DeviceDynamics(name, dt=0.03)
+        got = recognise(Wrap(d), d.n_state, d.n_ctrl)
+        assert got is not None and got.name == name and got.dt == 0.03
+        assert recognise(Wrap(d, scale=1.01), d.n_state, d.n_ctrl) is None          # a different model
+    assert recognise(Pendulum(), 2, 1, dt=0.04) is None                               # a different step
+    assert recognise(torch.nn.Linear(3, 3), 3, 1) is None                             # not a dynamics callable at all
+
+
+def test_tracking_mpc_recognises_env_module():
+    """policies.Tracking_MPC handed the env's torch module (as the reference's policies.py:571-572 does) solves on the
+    registered device model when the module is one: same trajectories as with the DeviceDynamics passed explicitly."""
+    import argparse, types
+    from diff_qp_mpc_amd import policies
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    from test_gpu_al import Pendulum, PendulumJac
+    B, T = 16, 5
+    outs = []
+    for dyn, jac in ((Pendulum(), PendulumJac()), (DeviceDynamics("pendulum_euler"), None)):
+        env = types.SimpleNamespace(nx=2, nu=1, nq=1, dt=0.05, dynamics=dyn, dynamics_derivatives=jac if jac is not None else dyn.jac,
+                                    action_space=types.SimpleNamespace(high=np.array([2.0]), low=np.array([-2.0])))
+        args = argparse.Namespace(T=T, nq=1, hdim=32, layer_type="mlp", deq_out_type=1, policy_out_type=1, deq_iter=2,
+                                  solver_type="al", qp_iter=1, eps=1e-2, warm_start=True, bsz=B, Q=torch.ones(2),
+                                  R=1e-2 * torch.ones(1), dtype="double", device="cuda")
+        torch.manual_seed(0)
+        trk = policies.Tracking_MPC(args, env)
+        assert isinstance(trk.dyn, DeviceDynamics)
+        gen = torch.Generator(device="cuda").manual_seed(1)
+        x0 = torch.rand(B, 2, device="cuda", generator=gen) - 0.5
+        x_ref = x0[:, None, :] * torch.linspace(1, 0, T, device="cuda")[None, :, None]
+        u_ref = torch.zeros(B, T, 1, device="cuda")
+        trk.reinitialize(x0, torch.ones(B, T, 1, device="cuda"))
+        xs, us = trk(x0, torch.cat([x_ref, u_ref], -1), x_ref, u_ref)
+        outs.append((xs.detach().cpu().numpy(), us.detach().cpu().numpy()))
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
