@@ -130,6 +130,28 @@ __device__ __forceinline__ void trsv_g(const double (&L)[1][N], const double (&r
         }
     }
 }
+// The forward sweep solves nx + 1 systems with each knot's L_tt.  With L = Lu D (Lu unit lower triangular, D = diag L)
+// the substitution runs on w = D y:  w_k = b_k - sum_{j<k} (L[k][j] / L[j][j]) w_j  -- per step one broadcast and one
+// fma, no scaling and no lane selects (trsv_g above: a multiply and two selects per step and system); y = w rd at the
+// end.  unit_lower overwrites the lane's row of L by its row of Lu with a ZERO diagonal (rows of lanes beyond the
+// matrix are identity rows and become zero rows).
+template <int G, int N>
+__device__ __forceinline__ void unit_lower(double (&L)[1][N], const double (&rd)[1], int r)
+{
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double s = Grp<G>::rb(rd[0], k);
+        L[0][k] = (r > k) ? L[0][k] * s : 0.0;
+    }
+}
+template <int G, int N>
+__device__ __forceinline__ double trsv_unit(const double (&Lu)[1][N], double b)
+{
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) b = fma(-Lu[0][k], Grp<G>::rb(b, k), b);
+    return b;           // w; the caller scales by rd
+}
+
 // b <- L^-T b for a row-distributed lower-triangular NT x NT matrix in registers
 template <int G, int NT>
 __device__ __forceinline__ void trsvT_rows(const double (&L)[1][NT], const double (&rd)[1], double (&b)[1], int r)
@@ -167,6 +189,17 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
 
     constexpr bool PRE = NT <= 8;        // small models: prefetched knot inputs, delayed factor stores (below)
     if constexpr (!PRE) {
+        static_assert(G == 16, "the large-model sweep keeps one knot per DPP row");
+        // transposed copy of M_t (nt rows over the lanes, nx columns in registers): column j of group p at
+        // trs[p PS + j TS + row]; TS = 18 doubles puts the 16 lanes' 16-byte column reads on 16 distinct bank quads, PS
+        // shifts neighbouring groups by half the banks for the row-wise writes.  Columns nx .. 15 stay zero: lanes
+        // beyond nx read them and so subtract nothing.
+        constexpr int TS = 18, PS = 16 * TS + 16;
+        __shared__ __attribute__((aligned(16))) double trs[(64 / G) * PS];
+        double *trow = trs + (lane / G) * PS + r;
+        const double *tcol = trs + (lane / G) * PS + r * TS;
+    #pragma unroll
+        for (int j = NX; j < G; ++j) trow[j * TS] = 0.0;
         for (int t = 0; t < T; ++t) {
             // ---- the knot and its successor's state (uniform loads)
             double z[NT], xn1[NX];
@@ -237,15 +270,19 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
                 for (int j = 0; j < NX; ++j) a = fma(Jc[j], Gr::rb(Jc[j], c), a);
                 H[0][c] = rho * a + ((r == c) ? dg : 0.0);
             }
+            // row r of M_prev^T M_prev and of M_prev^T y_prev from the transposed copy: sum_k M[k][r] M[k][j] with the
+            // left factor in the lane's own registers -- one broadcast + one fma per term, no group sums and no selects
+            // (12 x 13 / 2 group sums of 4 DPP steps each were a quarter of the knot)
+            double Mt[G];
             if (t > 0) {
     #pragma unroll
-                for (int i = 0; i < NX; ++i) {
+                for (int k = 0; k < G; ++k) Mt[k] = tcol[k];
     #pragma unroll
-                    for (int j = 0; j <= i; ++j) {
-                        const double tot = Gr::sum(Mprev[i] * Mprev[j]);
-                        if (r == i) H[0][j] -= tot;
-                        if (r == j && i != j) H[0][i] -= tot;
-                    }
+                for (int j = 0; j < NX; ++j) {
+                    double a = 0.0;
+    #pragma unroll
+                    for (int k = 0; k < NT; ++k) a = fma(Mt[k], Gr::rb(Mprev[j], k), a);
+                    H[0][j] -= a;
                 }
             }
     #pragma unroll
@@ -254,34 +291,39 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             // ---- right-hand side: y_t = L_tt^-1 (-g_t - L_{t,t-1} y_{t-1})
             double y[1] = {inT ? -g : 0.0};
             if (t > 0) {
+                double a = 0.0;
     #pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    const double tot = Gr::sum(Mprev[i] * yprev[0]);
-                    if (r == i) y[0] -= tot;
-                }
+                for (int k = 0; k < NT; ++k) a = fma(Mt[k], Gr::rb(yprev[0], k), a);
+                y[0] -= a;
             }
-            trsv_g<G, NT>(H, rd, y, r);
-            // ---- M_t = L_tt^-1 H_{t+1,t}^T: column j of it is the distributed vector -rho J[j][:]
-            double M[NX];
-    #pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                double v[1] = {-rho * Jc[j]};
-                trsv_g<G, NT>(H, rd, v, r);
-                M[j] = inT ? v[0] : 0.0;
-            }
-            // ---- keep the knot's factor rows (banded form) and y_t
+            // ---- keep the knot's factor rows (banded form), then turn the registers into the unit-triangular form
+            double *o = fac + ((long long)t * NT + r) * C::ROW;
             if (live && inT) {
-                double *o = fac + ((long long)t * NT + r) * C::ROW;
     #pragma unroll
                 for (int c = 0; c < NT; ++c) o[c] = H[0][c];
                 o[NT] = rd[0];
+            }
+            unit_lower<G, NT>(H, rd, r);
+            const double rdm = inT ? rd[0] : 0.0, nrho_rd = -rho * rdm;
+            y[0] = trsv_unit<G, NT>(H, y[0]) * rdm;
+            // ---- M_t = L_tt^-1 H_{t+1,t}^T: column j of it is the distributed vector -rho J[j][:]
+            double M[NX];
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) M[j] = trsv_unit<G, NT>(H, Jc[j]) * nrho_rd;
+            if (live && inT) {
     #pragma unroll
                 for (int j = 0; j < NX; ++j) o[NT + 1 + j] = M[j];
+                P.upd[b * (long long)T * NT + t * NT + r] = y[0];        // y parked in the output
             }
-            if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = y[0];        // y parked in the output
     #pragma unroll
             for (int j = 0; j < NX; ++j) { Mprev[j] = M[j]; mu_prev[j] = mu[j]; }
             yprev[0] = inT ? y[0] : 0.0;
+            // M_t transposed through LDS for the next knot (read after that knot's model evaluation); a workgroup is one
+            // wavefront: DS operations complete in order
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) trow[j * TS] = M[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     } else {
         // ---- a knot's inputs.  Small models (nt <= 8, where the registers allow it) load knot t + 1 while knot t
@@ -328,6 +370,13 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             }
         };
         if constexpr (PRE) load_knot(0);
+        // transposed copy of M_t, as in the large-model sweep, for groups of G lanes
+        constexpr int TS = G + 2, PS = G * TS + (G == 16 ? 16 : 0);
+        __shared__ __attribute__((aligned(16))) double trs[(64 / G) * PS];
+        double *trow = trs + (lane / G) * PS + r;
+        const double *tcol = trs + (lane / G) * PS + r * TS;
+    #pragma unroll
+        for (int j = NX; j < G; ++j) trow[j * TS] = 0.0;
 
         for (int t = 0; t < T; ++t) {
             if constexpr (!PRE) {
@@ -397,15 +446,16 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
                 for (int j = 0; j < NX; ++j) a = fma(Jc[j], Gr::rb(Jc[j], c), a);
                 H[0][c] = rho * a + ((r == c) ? dg : 0.0);
             }
+            double Mt[G];              // row r of M_prev^T M_prev and M_prev^T y_prev from the transposed copy (as above)
             if (t > 0) {
     #pragma unroll
-                for (int i = 0; i < NX; ++i) {
+                for (int k = 0; k < G; ++k) Mt[k] = tcol[k];
     #pragma unroll
-                    for (int j = 0; j <= i; ++j) {
-                        const double tot = Gr::sum(Mprev[i] * Mprev[j]);
-                        if (r == i) H[0][j] -= tot;
-                        if (r == j && i != j) H[0][i] -= tot;
-                    }
+                for (int j = 0; j < NX; ++j) {
+                    double a = 0.0;
+    #pragma unroll
+                    for (int k = 0; k < NT; ++k) a = fma(Mt[k], Gr::rb(Mprev[j], k), a);
+                    H[0][j] -= a;
                 }
             }
     #pragma unroll
@@ -414,34 +464,32 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             // ---- right-hand side: y_t = L_tt^-1 (-g_t - L_{t,t-1} y_{t-1})
             double y[1] = {inT ? -g : 0.0};
             if (t > 0) {
+                double a = 0.0;
     #pragma unroll
-                for (int i = 0; i < NX; ++i) {
-                    const double tot = Gr::sum(Mprev[i] * yprev[0]);
-                    if (r == i) y[0] -= tot;
-                }
+                for (int k = 0; k < NT; ++k) a = fma(Mt[k], Gr::rb(yprev[0], k), a);
+                y[0] -= a;
             }
-            trsv_g<G, NT>(H, rd, y, r);
+            // ---- keep the knot's factor rows (banded form; written while the next knot computes), then the solves on the
+            // unit-triangular form
+    #pragma unroll
+            for (int c = 0; c < NT; ++c) sH[c] = H[0][c];
+            unit_lower<G, NT>(H, rd, r);
+            const double rdm = inT ? rd[0] : 0.0, nrho_rd = -rho * rdm;
+            y[0] = trsv_unit<G, NT>(H, y[0]) * rdm;
             // ---- M_t = L_tt^-1 H_{t+1,t}^T: column j of it is the distributed vector -rho J[j][:]
             double M[NX];
     #pragma unroll
-            for (int j = 0; j < NX; ++j) {
-                double v[1] = {-rho * Jc[j]};
-                trsv_g<G, NT>(H, rd, v, r);
-                M[j] = inT ? v[0] : 0.0;
-            }
-            // ---- keep the knot's factor rows (banded form) and y_t
-            if constexpr (PRE) {
+            for (int j = 0; j < NX; ++j) M[j] = trsv_unit<G, NT>(H, Jc[j]) * nrho_rd;
     #pragma unroll
-                for (int c = 0; c < NT; ++c) sH[c] = H[0][c];
-    #pragma unroll
-                for (int j = 0; j < NX; ++j) sM[j] = M[j];
-                srd = rd[0]; sy = y[0];
-            } else {
-                store_knot(t, H[0], rd[0], M, y[0]);
-            }
+            for (int j = 0; j < NX; ++j) sM[j] = M[j];
+            srd = rd[0]; sy = y[0];
     #pragma unroll
             for (int j = 0; j < NX; ++j) { Mprev[j] = M[j]; mu_prev[j] = mu[j]; }
             yprev[0] = inT ? y[0] : 0.0;
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) trow[j * TS] = M[j];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         if constexpr (PRE) store_knot(T - 1, sH, srd, sM, sy);
     }
