@@ -6,7 +6,11 @@ fused kernels.
     Tracking_MPC   policies.py:567-686   p = -(Q x_ref); AL_mpc.MPC ("al", the reference's default,
                                          deqmpc/train.py:61) or qp_wrapper.MPC ("ip")
     DEQMPCPolicy   policies.py:432-529   deq_iter x [DEQLayer -> Tracking_MPC]; every iterate is returned
-    compute_loss_deqmpc / add_loss_based_on_out_type   policies.py:800-833
+    FFDNetwork / NNMPCPolicy   policies.py:532-716   feed-forward reference + the same Tracking_MPC
+    NNPolicy       policies.py:719-784   behaviour-cloning baseline (no solver)
+    compute_loss / compute_loss_deqmpc / _deq / _bc / add_loss_based_on_out_type   policies.py:787-848
+    (DEQPolicy, policies.py:25-128, is dead code in the reference: its solver is an unbound `anderson` using the
+    removed torch.solve and an undefined self.kwargs; not mirrored)
     train_step     the body of deqmpc/train.py:135-175 for one batch, plus what the reference does not
                    have: data-parallel training -- each rank solves its own shard of trajectories
                    (the solves never communicate) and the DEQLayer gradients are summed over ranks with
@@ -40,7 +44,11 @@ class DEQLayer(nn.Module):
         self.layer_type = getattr(args, "layer_type", "mlp")
         self.out_type = args.deq_out_type
         if self.layer_type != "mlp":
-            raise NotImplementedError("only the MLP DEQLayer is mirrored (the solver call pattern is the same)")
+            # the reference's other variants do not construct: "gcn" reads self.num_groups, which nothing sets
+            # (policies.py:386-390 -> AttributeError), and chains Linear(hdim, 4 hdim) into Linear(3 hdim, hdim)
+            # (:352-356); "gat" is a bare `NotImplementedError` expression in every branch (:264,285,299,...)
+            raise NotImplementedError("layer_type %r: only the MLP DEQLayer exists in working form in the reference "
+                                      "(its gcn variant fails in __init__, gat is a stub)" % self.layer_type)
         if self.out_type not in (1, 2):
             raise NotImplementedError("deq_out_type 1 / 2 (state prediction), as DEQMPCPolicy.forward handles")
         self.in_dim = self.nx + self.nx * (self.T - 1)                             # policies.py:313-315
@@ -182,6 +190,85 @@ class DEQMPCPolicy(nn.Module):
         return trajs, dyn_res
 
 
+class FFDNetwork(nn.Module):
+    """Feed-forward reference generator of NNMPCPolicy (policies.py:532-564): state -> T configurations, as offsets
+    from the current configuration.  Layer names as the reference's (fc1 .. fc3 / `net`) for its state dicts."""
+
+    def __init__(self, args, env):
+        super().__init__()
+        self.args = args
+        self.nu, self.nx, self.nq, self.T = env.nu, env.nx, args.nq, args.T
+        self.fc1, self.ln1, self.relu1 = nn.Linear(self.nx, 256), nn.LayerNorm(256), nn.ReLU()
+        self.fc2, self.ln2, self.relu2 = nn.Linear(256, 256), nn.LayerNorm(256), nn.ReLU()
+        self.fc3 = nn.Linear(256, self.nq * self.T)
+        self.net = nn.Sequential(self.fc1, self.ln1, self.relu1, self.fc2, self.ln2, self.relu2, self.fc3)
+
+    def forward(self, x):
+        return self.net(x).view(-1, self.T, self.nq) + x[:, None, :self.nq]
+
+
+class NNMPCPolicy(nn.Module):
+    """Feed-forward network proposes a configuration trajectory, the differentiable MPC tracks it
+    (policies.py:689-716).  The reference's forward hands Tracking_MPC two arguments in a time-major layout its
+    four-argument, batch-major forward (policies.py:640) no longer takes; here the same reference -- configurations
+    from the network, zero velocities, zero controls -- goes through the current signature.  Call `reinitialize` (or
+    pass `mask`) before the first AL solve, as AL_mpc.MPC requires (AL_mpc.py:432)."""
+
+    def __init__(self, args, env):
+        super().__init__()
+        self.args = args
+        self.nu, self.nx, self.nq, self.T, self.dt = env.nu, env.nx, args.nq, args.T, env.dt
+        self.device = args.device
+        self.out_type = args.policy_out_type
+        self.model = FFDNetwork(args, env).to(self.device)
+        self.tracking_mpc = Tracking_MPC(args, env)
+
+    def reinitialize(self, x, mask):
+        self.tracking_mpc.reinitialize(x, mask)
+
+    def forward(self, x, mask=None):
+        q_ref = self.model(x)
+        x_ref = torch.cat([q_ref, torch.zeros(q_ref.shape[:-1] + (self.nx - self.nq,), dtype=q_ref.dtype, device=q_ref.device)], dim=-1)
+        u_ref = torch.zeros(x.shape[0], self.T, self.nu, dtype=q_ref.dtype, device=q_ref.device)
+        if self.args.solver_type == "al":
+            if mask is None:
+                mask = torch.ones(x.shape[0], self.T, 1, dtype=x.dtype, device=x.device)
+            self.tracking_mpc.reinitialize(x, mask)
+        return self.tracking_mpc(x, torch.cat([x_ref, u_ref], dim=-1), x_ref, u_ref)
+
+
+class NNPolicy(nn.Module):
+    """Behaviour-cloning baseline without a solver (policies.py:719-784): state -> trajectory of actions (out_type 0),
+    states (1), both (2) or configurations with finite-difference velocities (3)."""
+
+    def __init__(self, args, env):
+        super().__init__()
+        self.args = args
+        self.nu, self.nx, self.nq, self.T, self.dt = env.nu, env.nx, args.nq, args.T, env.dt
+        self.device, self.hdim, self.out_type = args.device, args.hdim, args.policy_out_type
+        self.out_dim = {0: self.nu, 1: self.nx, 2: self.nx + self.nu, 3: self.nq}[self.out_type] * self.T
+        self.model = nn.Sequential(nn.Linear(self.nx, self.hdim), nn.LayerNorm(self.hdim), nn.ReLU(),
+                                   nn.Linear(self.hdim, self.hdim), nn.LayerNorm(self.hdim), nn.ReLU())
+        self.model.add_module("out", nn.Linear(self.hdim, self.out_dim))
+
+    def forward(self, x):
+        y = self.model(x)
+        if self.out_type == 0:
+            return None, y.view(-1, self.T, self.nu)
+        if self.out_type == 1:
+            return y.view(-1, self.T, self.nx), None
+        if self.out_type == 2:
+            cut = self.nx * self.T
+            return y[:, :cut].view(-1, self.T, self.nx), y[:, cut:].view(-1, self.T, self.nu)
+        # out_type 3.  The reference differences the FLAT (bsz, nq T) output along its last axis' neighbour
+        # (`pos[:, 1:] - pos[:, :-1]`, policies.py:779-781), which mixes coordinates for nq > 1 and leaves shapes that
+        # only concatenate for nq = 1; here the difference is taken per knot, which is the same thing at nq = 1.
+        pos = y.view(-1, self.T, self.nq)
+        vel = (pos[:, 1:] - pos[:, :-1]) / self.dt
+        vel = torch.cat([vel, vel[:, -1:]], dim=1)
+        return torch.cat([pos, vel], dim=-1), None
+
+
 def add_loss_based_on_out_type(policy, out_type, gt_states, gt_actions, gt_mask, nominal_states, nominal_actions):
     """policies.py:818-833: masked L1 on actions (0, 2), states (1, 2) or configurations (3)."""
     loss = 0.0
@@ -202,6 +289,30 @@ def compute_loss_deqmpc(policy, gt_states, gt_actions, gt_mask, trajs):
         loss = loss + add_loss_based_on_out_type(policy, policy.out_type, gt_states, gt_actions, gt_mask, ns, na)
     _, ns, na = trajs[-1]
     return loss, add_loss_based_on_out_type(policy, policy.out_type, gt_states, gt_actions, gt_mask, ns, na)
+
+
+def compute_loss_deq(policy, gt_states, gt_actions, gt_mask, trajs):
+    """policies.py:787-797 (DEQ pre-training, `policy` = the DEQLayer): every round's state prediction, out_type 1."""
+    loss = 0.0
+    for (_, ns, na) in trajs:
+        loss = loss + add_loss_based_on_out_type(policy, 1, gt_states, gt_actions, gt_mask, ns, na)
+    _, ns, na = trajs[-1]
+    return loss, add_loss_based_on_out_type(policy, 1, gt_states, gt_actions, gt_mask, ns, na)
+
+
+def compute_loss_bc(policy, gt_states, gt_actions, gt_mask, trajs):
+    """policies.py:811-816: one (states, actions) pair from NNPolicy / NNMPCPolicy."""
+    ns, na = trajs
+    return add_loss_based_on_out_type(policy, policy.out_type, gt_states, gt_actions, gt_mask, ns, na), torch.zeros(1)
+
+
+def compute_loss(policy, gt_states, gt_actions, gt_mask, trajs, args):
+    """policies.py:836-848: the loss of the training mode `args` selects."""
+    if args.deq:
+        if args.en_qp_solve:
+            return compute_loss_deqmpc(policy, gt_states, gt_actions, gt_mask, trajs)
+        return compute_loss_deq(policy.model, gt_states, gt_actions, gt_mask, trajs)
+    return compute_loss_bc(policy, gt_states, gt_actions, gt_mask, trajs)
 
 
 def allreduce_gradients(module, group=None, world_size=None):

@@ -155,3 +155,43 @@ def test_graphed_train_step_matches_eager():
     np.testing.assert_allclose(e2, e1, rtol=1e-6)
     np.testing.assert_allclose(gr, e1, rtol=1e-6)
     assert gr[-1] < gr[0]
+
+
+def test_nnmpc_policy_and_bc_losses():
+    """NNMPCPolicy (policies.py:689-716): the feed-forward reference tracked by the AL solver; the solution starts at x,
+    follows the dynamics to the solver's tolerance, and the behaviour-cloning loss reaches the network's weights
+    through the solver's implicit derivative."""
+    import argparse, types
+    from diff_qp_mpc_amd import policies
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    B, T = 32, 6
+    dyn = DeviceDynamics("pendulum_euler")
+    env = types.SimpleNamespace(nx=2, nu=1, nq=1, dt=dyn.dt, dynamics=dyn, dynamics_derivatives=dyn.jac,
+                                action_space=types.SimpleNamespace(high=np.array([2.0]), low=np.array([-2.0])))
+    args = argparse.Namespace(T=T, nq=1, hdim=32, policy_out_type=1, solver_type="al", qp_iter=1, eps=1e-2, warm_start=True,
+                              bsz=B, Q=torch.ones(2), R=1e-2 * torch.ones(1), dtype="double", device="cuda", deq=False,
+                              en_qp_solve=False)
+    torch.manual_seed(0)
+    pol = policies.NNMPCPolicy(args, env)
+    x = torch.rand(B, 2, device="cuda") - 0.5
+    xs, us = pol(x)
+    assert xs.shape == (B, T, 2) and us.shape == (B, T, 1)
+    assert float((xs[:, 0] - x).abs().max()) < 1e-5
+    # the wiring: the same solve as Tracking_MPC called directly on [network configurations, zero velocities], zero controls
+    q_ref = pol.model(x).detach()
+    x_ref = torch.cat([q_ref, torch.zeros_like(q_ref)], -1)
+    u_ref = torch.zeros(B, T, 1, device="cuda")
+    trk = pol.tracking_mpc
+    trk.reinitialize(x, torch.ones(B, T, 1, device="cuda"))
+    xs2, us2 = trk(x, torch.cat([x_ref, u_ref], -1), x_ref, u_ref)
+    np.testing.assert_array_equal(xs.detach().cpu().numpy(), xs2.detach().cpu().numpy())
+    np.testing.assert_array_equal(us.detach().cpu().numpy(), us2.detach().cpu().numpy())
+    # and the solver did its job on the tracking problem: lower tracking cost + smaller dynamics gap than the proposal
+    gap = dyn(xs[:, :-1].reshape(-1, 2).double(), us[:, :-1].reshape(-1, 1).double()).reshape(B, T - 1, 2) - xs[:, 1:]
+    gap_ref = dyn(x_ref[:, :-1].reshape(-1, 2).double(), u_ref[:, :-1].reshape(-1, 1).double()).reshape(B, T - 1, 2) - x_ref[:, 1:]
+    assert float(gap.abs().mean()) < float(gap_ref.abs().mean())
+    gs = x[:, None, :] * torch.linspace(1, 0, T, device="cuda")[None, :, None]
+    loss, _ = policies.compute_loss(pol, gs, torch.zeros(B, T, 1, device="cuda"), torch.ones(B, T, device="cuda"), (xs, us), args)
+    loss.backward()
+    g = pol.model.fc3.weight.grad
+    assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
