@@ -32,6 +32,45 @@ from . import qp_wrapper as ip_mpc
 RECOGNISE_ENV_DYNAMICS = True
 
 
+# batch rows from which the DEQLayer's linears take their weight gradient in slices (SlicedLinear below)
+SLICED_WGRAD_FROM = 8192
+
+
+class SlicedLinear(torch.autograd.Function):
+    """y = x W^T + b whose weight gradient dW = dY^T X is formed in row slices.  At the reference's training sizes the
+    batch (the GEMM's reduction length) is 10^4 - 10^5 rows against a 128 x 128 result: the library heuristic runs that
+    as ONE pass of sixteen 32 x 32 tiles over all rows (226 us per call at B = 65536 on MI355X, 11 % of a config-5
+    training step, profiles/r3/config5_kernel_stats.csv); as a batched product over S row slices plus a sum it fills
+    the chip.  Forward and dX are the plain library calls."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = b is not None
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        rows = x.shape[0]
+        s = 1
+        while rows % (2 * s) == 0 and rows // (2 * s) >= 512:
+            s *= 2
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        gw = None
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(gy.view(s, rows // s, -1).transpose(1, 2), x.contiguous().view(s, rows // s, -1)).sum(0)
+        gb = gy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
+def _linear(lin, x):
+    if x.is_cuda and x.dim() == 2 and x.shape[0] >= SLICED_WGRAD_FROM and torch.is_grad_enabled():
+        return SlicedLinear.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 class DEQLayer(nn.Module):
     """One DEQ iteration of the reference's trajectory network, MLP flavour (policies.py:191-430,
     layer_type "mlp", deq_out_type 1 or 2): input = current reference trajectory, hidden state z."""
@@ -64,13 +103,13 @@ class DEQLayer(nn.Module):
         return torch.zeros(bsz, self.hdim, dtype=torch.float32, device=p.device)
 
     def deq_layer(self, x, z):                                                    # policies.py:277-283
-        z = self.lndeq1(self.reludeq1(self.fcdeq1(z)))
-        return self.lndeq3(self.reludeq2(z + self.lndeq2(x + self.fcdeq2(z))))
+        z = self.lndeq1(self.reludeq1(_linear(self.fcdeq1, z)))
+        return self.lndeq3(self.reludeq2(z + self.lndeq2(x + _linear(self.fcdeq2, z))))
 
     def forward(self, x, z):
-        z_out = self.deq_layer(self.inp_layer(x), z)
+        z_out = self.deq_layer(self.inp_layer[1](_linear(self.inp_layer[0], x)), z)
         steps = self.T - 1 if self.out_type == 1 else self.T
-        dx_ref = self.out_layer(z_out).view(-1, steps, self.nx)
+        dx_ref = _linear(self.out_layer[0], z_out).view(-1, steps, self.nx)
         vel_ref = dx_ref[..., self.nq:]
         pos_ref = dx_ref[..., :self.nq] * self.dt + x[:, None, :self.nq]           # policies.py:221-223
         return torch.cat([pos_ref, vel_ref], dim=-1), z_out

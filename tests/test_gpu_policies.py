@@ -195,3 +195,23 @@ def test_nnmpc_policy_and_bc_losses():
     loss.backward()
     g = pol.model.fc3.weight.grad
     assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().max()) > 0
+
+
+def test_sliced_weight_gradient_linear():
+    """policies.SlicedLinear: same forward, same gradients as torch.nn.functional.linear (fp32 summation order aside)."""
+    from diff_qp_mpc_amd import policies
+    torch.manual_seed(0)
+    for rows in (8192, 12288, 8200):
+        x = torch.randn(rows, 35, device="cuda", requires_grad=True)
+        lin = torch.nn.Linear(35, 128).cuda()
+        g = torch.randn(rows, 128, device="cuda")
+        y0 = lin(x); y0.backward(g)
+        want = (y0.detach().clone(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+        x.grad = None; lin.zero_grad()
+        y1 = policies._linear(lin, x)
+        assert y1.grad_fn is not None and "SlicedLinear" in type(y1.grad_fn).__name__
+        y1.backward(g)
+        torch.testing.assert_close(y1.detach(), want[0], rtol=0, atol=0)
+        torch.testing.assert_close(x.grad, want[1], rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(lin.weight.grad, want[2], rtol=1e-4, atol=2e-3)
+        torch.testing.assert_close(lin.bias.grad, want[3], rtol=1e-4, atol=2e-3)
