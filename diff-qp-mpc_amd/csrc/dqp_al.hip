@@ -726,19 +726,29 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
     const double *lam = P.lam + b * (long long)ncon, *x0 = P.x0 + b * (long long)n;
     const double rho = P.rho[b];
     double *zb = lsg_lds + (size_t)grp * T * ZS;
-    // ---- the problem, once: element e = r + TPI i of the (T, nt) arrays
-    double ex[EPL], eu[EPL], eq[EPL], el[EPL], lu[EPL], ll[EPL], hi[EPL], lo[EPL];
+    // ---- the problem, once: element e = r + TPI i of the (T, nt) arrays; the box rows (multipliers, bounds) only exist
+    // for the T m control elements and are distributed over the lanes on their own (element c = r + TPI i of the (T, m)
+    // array, with its own copy of the iterate and the update): eight arrays of EPL doubles per lane were 144 - 256
+    // registers before the model's own, one wavefront per SIMD; four + six short ones leave room for two
+    constexpr int UPL = (TMAX * m + TPI - 1) / TPI;
+    double ex[EPL], eu[EPL], eq[EPL], el[EPL];
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
         const int e = r + TPI * i, ec = e < nzq ? e : 0, t = ec / nt, j = ec - t * nt;
         const bool ok = e < nzq;
         ex[i] = ok ? xu[ec] : 0.0; eu[i] = (ok && P.ncand > 0) ? up[ec] : 0.0;
         eq[i] = ok ? Qd[ec] : 0.0; el[i] = ok ? q[ec] : 0.0;
-        const bool isu = ok && j >= n;
-        const int iu = isu ? j - n : 0, row = neq + t * 2 * m + iu;
-        lu[i] = isu ? lam[row] : 0.0; ll[i] = isu ? lam[row + m] : 0.0;
-        hi[i] = isu ? P.uu[iu] : INFINITY; lo[i] = isu ? P.ul[iu] : -INFINITY;
         if (ok && t == 0 && j < n) { ex[i] = x0[j]; eu[i] = 0.0; }            // x_0 pinned to x0 (al_utils.py:515)
+    }
+    double cx[UPL], cu[UPL], lu[UPL], ll[UPL], hi[UPL], lo[UPL];
+#pragma unroll
+    for (int i = 0; i < UPL; ++i) {
+        const int c = r + TPI * i, cc = c < T * m ? c : 0, t = cc / m, iu = cc - t * m;
+        const bool ok = c < T * m;
+        const int ec = t * nt + n + iu, row = neq + t * 2 * m + iu;
+        cx[i] = ok ? xu[ec] : 0.0; cu[i] = (ok && P.ncand > 0) ? up[ec] : 0.0;
+        lu[i] = ok ? lam[row] : 0.0; ll[i] = ok ? lam[row + m] : 0.0;
+        hi[i] = ok ? P.uu[iu] : INFINITY; lo[i] = ok ? P.ul[iu] : -INFINITY;
     }
     double ly[n];
 #pragma unroll
@@ -759,9 +769,14 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
                 const double z = fma(step, eu[i], ex[i]);
                 zb[t * ZS + j] = z;
                 acc += (0.5 * eq[i] * z + el[i]) * z;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < UPL; ++i) {
+            if (r + TPI * i < T * m) {
+                const double z = fma(step, cu[i], cx[i]);
                 const double vh = z - hi[i], vl = lo[i] - z;
-                if (j >= n)
-                    acc += lu[i] * vh + ll[i] * vl + 0.5 * rho * (fmax(vh, 0.0) * fmax(vh, 0.0) + fmax(vl, 0.0) * fmax(vl, 0.0));
+                acc += lu[i] * vh + ll[i] * vl + 0.5 * rho * (fmax(vh, 0.0) * fmax(vh, 0.0) + fmax(vl, 0.0) * fmax(vl, 0.0));
             }
         }
         group_sync();
