@@ -172,3 +172,23 @@ def test_tracking_mpc_recognises_env_module():
         outs.append((xs.detach().cpu().numpy(), us.detach().cpu().numpy()))
     np.testing.assert_array_equal(outs[0][0], outs[1][0])
     np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+def test_device_sincos_against_libm_over_ranges():
+    """The models' device sin/cos (csrc/dqp_dyn_models.h sincos_) through the pendulum model, whose step is x' = [th + dt (w + dt (u + 10 sin th)), w + dt (u +
+    10 sin th)]: against numpy's libm over six decades of angles, near multiples of pi/2, and at non-finite input."""
+    from diff_qp_mpc_amd.dynamics import DeviceDynamics
+    d = DeviceDynamics("pendulum_euler", dt=1.0)
+    rng = np.random.default_rng(0)
+    for scale in (1.0, 10.0, 1e3, 1e5, 1e7, 1e12):
+        th = rng.uniform(-scale, scale, 20000)
+        th[::5] = np.rint(th[::5] / (np.pi / 2)) * (np.pi / 2) + rng.uniform(-1e-9, 1e-9, th[::5].shape)
+        x = torch.tensor(np.stack([th, np.zeros_like(th)], 1), device="cuda")
+        u = torch.zeros(len(th), 1, dtype=torch.float64, device="cuda")
+        w = d(x, u)[:, 1].cpu().numpy()                       # = 10 sin th
+        np.testing.assert_allclose(w, 10.0 * np.sin(th), rtol=0, atol=4e-15)
+        _, (Jx, _) = d.jac(x, u)                                # d w' / d th = 10 cos th
+        np.testing.assert_allclose(Jx[:, 1, 0].cpu().numpy(), 10.0 * np.cos(th), rtol=0, atol=4e-15)
+    bad = torch.tensor([[float("inf"), 0.0], [float("nan"), 0.0]], dtype=torch.float64, device="cuda")
+    out = d(bad, torch.zeros(2, 1, dtype=torch.float64, device="cuda"))
+    assert bool(torch.isnan(out[:, 1]).all())
