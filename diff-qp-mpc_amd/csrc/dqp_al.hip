@@ -710,7 +710,7 @@ __device__ __forceinline__ void group_sync()
 }
 
 template <class Map, int TPI, int TMAX>
-__global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
+__global__ __launch_bounds__(256, ((TMAX * (Map::NX + Map::NU) + TPI - 1) / TPI >= 12) ? 2 : 1) void al_ls_group_kernel(LsAP P)
 {
     constexpr int n = Map::NX, m = Map::NU, nt = n + m, ZS = nt | 1;
     constexpr int EPL = (TMAX * nt + TPI - 1) / TPI;       // elements of the (T, nt) arrays per lane, T <= TMAX
@@ -731,14 +731,27 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
     // array, with its own copy of the iterate and the update): eight arrays of EPL doubles per lane were 144 - 256
     // registers before the model's own, one wavefront per SIMD; four + six short ones leave room for two
     constexpr int UPL = (TMAX * m + TPI - 1) / TPI;
-    double ex[EPL], eu[EPL], eq[EPL], el[EPL];
+    // Long knots (EPL >= 12: the quadrotor's 16 elements per lane): the quadratic cost along the search direction is
+    // the polynomial c0 + s c1 + s^2 c2 of the step -- three numbers per lane instead of the cost's two arrays (64
+    // registers at nt = 16, which kept the kernel at one wavefront per SIMD) and two fmas per candidate instead of 2 EPL.
+    constexpr bool POLY = EPL >= 12;
+    double ex[EPL], eu[EPL], eq[POLY ? 1 : EPL], el[POLY ? 1 : EPL];
+    double c0 = 0.0, c1 = 0.0, c2 = 0.0;
 #pragma unroll
     for (int i = 0; i < EPL; ++i) {
         const int e = r + TPI * i, ec = e < nzq ? e : 0, t = ec / nt, j = ec - t * nt;
         const bool ok = e < nzq;
         ex[i] = ok ? xu[ec] : 0.0; eu[i] = (ok && P.ncand > 0) ? up[ec] : 0.0;
-        eq[i] = ok ? Qd[ec] : 0.0; el[i] = ok ? q[ec] : 0.0;
+        const double qd = ok ? Qd[ec] : 0.0, ql = ok ? q[ec] : 0.0;
         if (ok && t == 0 && j < n) { ex[i] = x0[j]; eu[i] = 0.0; }            // x_0 pinned to x0 (al_utils.py:515)
+        if constexpr (POLY) {
+            const double qx = qd * ex[i];
+            c0 += (0.5 * qx + ql) * ex[i];
+            c1 += (qx + ql) * eu[i];
+            c2 += 0.5 * qd * eu[i] * eu[i];
+        } else {
+            eq[i] = qd; el[i] = ql;
+        }
     }
     double cx[UPL], cu[UPL], lu[UPL], ll[UPL], hi[UPL], lo[UPL];
 #pragma unroll
@@ -750,9 +763,14 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
         lu[i] = ok ? lam[row] : 0.0; ll[i] = ok ? lam[row + m] : 0.0;
         hi[i] = ok ? P.uu[iu] : INFINITY; lo[i] = ok ? P.ul[iu] : -INFINITY;
     }
-    double ly[n];
+    // multipliers of the lane's dynamics rows: registers, or -- long knots -- the group's LDS rows behind its iterate
+    double ly[POLY ? 1 : n];
+    double *lyb = lsg_lds + (size_t)(256 / TPI) * T * ZS + ((size_t)grp * T + r) * n;
 #pragma unroll
-    for (int j = 0; j < n; ++j) ly[j] = (r < T - 1) ? lam[r * n + j] : 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double v = (r < T - 1) ? lam[r * n + j] : 0.0;
+        if constexpr (POLY) { if (r < T) lyb[j] = v; } else ly[j] = v;
+    }
     // candidates k = blockIdx.y, blockIdx.y + gridDim.y, ...: small batches are split over more wavefronts
     const bool fold = P.xu_w != nullptr && gridDim.y == 1 && P.ncand > 0;
     double best = 0.0;
@@ -760,7 +778,7 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
     bool isnan_ = false;
     for (int k = blockIdx.y; k < nc; k += gridDim.y) {
         const double step = P.ncand > 0 ? (double)exp2f(-(float)k) : 0.0;    // float steps, as the reference
-        double acc = 0.0;
+        double acc = POLY ? fma(step, fma(step, c2, c1), c0) : 0.0;
 #pragma unroll
         for (int i = 0; i < EPL; ++i) {
             const int e = r + TPI * i;
@@ -768,7 +786,7 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
                 const int t = e / nt, j = e - t * nt;
                 const double z = fma(step, eu[i], ex[i]);
                 zb[t * ZS + j] = z;
-                acc += (0.5 * eq[i] * z + el[i]) * z;
+                if constexpr (!POLY) acc += (0.5 * eq[i] * z + el[i]) * z;
             }
         }
 #pragma unroll
@@ -788,7 +806,7 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
 #pragma unroll
             for (int j = 0; j < n; ++j) {
                 const double res = zb[(r + 1) * ZS + j] - xn[j];
-                acc += (0.5 * rho * res + ly[j]) * res;
+                acc += (0.5 * rho * res + (POLY ? lyb[j] : ly[j])) * res;
             }
         }
         group_sync();
@@ -825,7 +843,8 @@ __global__ __launch_bounds__(256) void al_ls_group_kernel(LsAP P)
 template <class Map, int TPI, int TMAX = TPI> int launch_ls_group(const LsAP &P, hipStream_t st)
 {
     constexpr int ZS = (Map::NX + Map::NU) | 1, G = 256 / TPI;
-    const size_t lds = (size_t)G * P.T * ZS * sizeof(double);
+    constexpr bool POLY = (TMAX * (Map::NX + Map::NU) + TPI - 1) / TPI >= 12;
+    const size_t lds = (size_t)G * P.T * (ZS + (POLY ? Map::NX : 0)) * sizeof(double);
     const unsigned blocks = (unsigned)((P.B + G - 1) / G);
     // at least ~2 wavefronts per SIMD where the batch alone does not give them: split the candidates
     unsigned split = 1;
