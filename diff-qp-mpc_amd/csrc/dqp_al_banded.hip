@@ -47,7 +47,29 @@ struct BandP {
     int32_t *info;      // (B): 0 or 1 + knot of the first non-positive pivot
     double dt;
     int B, T;
+#ifdef DQP_BAND_STAMPS
+    unsigned long long *stamps;     // instrumented build (tools/stamps_band.py): 8 accumulated s_memtime phases per workgroup
+#endif
 };
+
+// Phase clock of the instrumented build (tools/stamps_band.py; compiled out otherwise).  Each stamp drains the memory
+// counters first, so the phases do not overlap as they do in the shipped kernel: the split shows where the cycles of a
+// knot go, not what removing a phase would save.
+#ifdef DQP_BAND_STAMPS
+static unsigned long long *g_band_stamps = nullptr;
+#define BAND_STAMP(k)                                                                          \
+    do {                                                                                       \
+        unsigned long long now_;                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) :: "memory"); \
+        stamp_acc[k] += now_ - stamp_last; stamp_last = now_;                                  \
+    } while (0)
+#define BAND_STAMP_INIT                                                                        \
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last;                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_last) :: "memory")
+#else
+#define BAND_STAMP(k)
+#define BAND_STAMP_INIT
+#endif
 
 // A dynamics the caller linearised itself (a torch module with its own Jacobians, deqmpc/envs.py:50-82,
 // rex_quadrotor.py:131-146): sizes only; the kernel reads f, df/dx, df/du from memory instead of evaluating a
@@ -58,7 +80,11 @@ template <int A, int B_> struct is_given<Given<A, B_>> { static constexpr bool v
 
 template <class Map> struct BandCfg {
     static constexpr int NX = Map::NX, NU = Map::NU, NT = NX + NU;
-    static constexpr int ROW = NT + 1 + NX;                  // per lane and knot: L row, 1/diag, M row
+    // per knot: ROW = nt + 1 + nx "columns" (L row entries, 1/diag, M row entries) of nt doubles each, one per lane of the
+    // knot: element c of lane r's row at [c nt + r], so that one store / load instruction moves nt consecutive doubles per
+    // problem.  (Lane-major rows -- [r ROW + c] -- made every instruction touch 64 separate cache lines: the factor is
+    // 111 KB per quadrotor problem, written by the forward sweep and read by the backward sweep of every Newton step.)
+    static constexpr int ROW = NT + 1 + NX;
     static_assert(NT <= 16, "one knot must fit a 16-lane DPP row");
 };
 
@@ -164,6 +190,33 @@ __device__ __forceinline__ void trsvT_rows(const double (&L)[1][NT], const doubl
     }
 }
 
+// b <- L^-T b by broadcasts: with the lane holding its COLUMN of L (Lt[k] = L[k][r]: row r of the upper triangular L^T)
+// the substitution U x = b runs like the forward one -- w = D x: w_r = b_r - sum_{k>r} L[k][r] / L[k][k] w_k, one
+// broadcast and one fma per step on a chain of 2 dependent instructions, instead of a group sum (a multiply and four
+// DPP + add rounds in sequence) per step.  The column comes from the row through the group's LDS tile `tile` (element
+// (row, col) at [col TS + row], as the forward sweep's transposed copy of M).
+template <int G, int NT, int TS>
+__device__ __forceinline__ double trsvT_bcast(const double (&L)[1][NT], double rdv, double b, double *trow, const double *tcol, int r)
+{
+#pragma unroll
+    for (int c = 0; c < NT; ++c) trow[c * TS] = L[0][c];              // L[r][c] -> tile (row r, col c)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double U[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) U[k] = tcol[k];                      // column r: L[k][r]
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 1; k < NT; ++k) {
+        const double sk = Grp<G>::rb(rdv, k);         // outside the select: a broadcast inside a divergent arm would read
+        U[k] = (r < k) ? U[k] * sk : 0.0;             // lane k while lane k is masked off (DPP returns 0 for it)
+    }
+#pragma unroll
+    for (int k = NT - 1; k >= 1; --k) b = fma(-U[k], Grp<G>::rb(b, k), b);
+    return b * rdv;
+}
+
 template <class Map, int G>
 __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
 {
@@ -188,6 +241,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
     for (int j = 0; j < NX; ++j) { Mprev[j] = 0.0; mu_prev[j] = 0.0; }
 
     constexpr bool PRE = NT <= 8;        // small models: prefetched knot inputs, delayed factor stores (below)
+    BAND_STAMP_INIT;
     if constexpr (!PRE) {
         static_assert(G == 16, "the large-model sweep keeps one knot per DPP row");
         // transposed copy of M_t (nt rows over the lanes, nx columns in registers): column j of group p at
@@ -208,6 +262,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             const bool dynrow = t < T - 1;
     #pragma unroll
             for (int j = 0; j < NX; ++j) xn1[j] = dynrow ? xu[(t + 1) * NT + j] : 0.0;
+            BAND_STAMP(0);          // knot loads (and the previous knot's stores)
             // ---- column r of J_t = [df/dx df/du] by one forward-mode seed per lane
             double Jc[NX], mu[NX];
             if constexpr (is_given<Map>::value) {
@@ -236,6 +291,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
                     mu[j] = dynrow ? lam[t * NX + j] + rho * res : 0.0;
                 }
             }
+            BAND_STAMP(1);          // model + Jacobian column
             // ---- gradient element r of this knot, and the diagonal terms of H_tt
             // (per-lane addresses: one coalesced load each instead of NT predicated ones)
             const int rr = inT ? r : 0;
@@ -287,7 +343,9 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             }
     #pragma unroll
             for (int c = 0; c < NT; ++c) H[0][c] = inT ? H[0][c] : ((r == c) ? 1.0 : 0.0);
+            BAND_STAMP(2);          // gradient, H = rho J^T J + diag - M^T M
             if (!chol_g<G, NT>(H, rd, r) && bad == 0) bad = t + 1;
+            BAND_STAMP(3);          // Cholesky
             // ---- right-hand side: y_t = L_tt^-1 (-g_t - L_{t,t-1} y_{t-1})
             double y[1] = {inT ? -g : 0.0};
             if (t > 0) {
@@ -297,11 +355,11 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
                 y[0] -= a;
             }
             // ---- keep the knot's factor rows (banded form), then turn the registers into the unit-triangular form
-            double *o = fac + ((long long)t * NT + r) * C::ROW;
+            double *o = fac + (long long)t * NT * C::ROW + r;
             if (live && inT) {
     #pragma unroll
-                for (int c = 0; c < NT; ++c) o[c] = H[0][c];
-                o[NT] = rd[0];
+                for (int c = 0; c < NT; ++c) o[(c) * NT] = H[0][c];
+                o[(NT) * NT] = rd[0];
             }
             unit_lower<G, NT>(H, rd, r);
             const double rdm = inT ? rd[0] : 0.0, nrho_rd = -rho * rdm;
@@ -312,7 +370,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             for (int j = 0; j < NX; ++j) M[j] = trsv_unit<G, NT>(H, Jc[j]) * nrho_rd;
             if (live && inT) {
     #pragma unroll
-                for (int j = 0; j < NX; ++j) o[NT + 1 + j] = M[j];
+                for (int j = 0; j < NX; ++j) o[(NT + 1 + j) * NT] = M[j];
                 P.upd[b * (long long)T * NT + t * NT + r] = y[0];        // y parked in the output
             }
     #pragma unroll
@@ -324,6 +382,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             for (int j = 0; j < NX; ++j) trow[j * TS] = M[j];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            BAND_STAMP(4);          // forward substitutions (y, M), factor stores, transposed copy
         }
     } else {
         // ---- a knot's inputs.  Small models (nt <= 8, where the registers allow it) load knot t + 1 while knot t
@@ -360,12 +419,12 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
         double sH[NT], sM[NX], srd = 0.0, sy = 0.0;              // PRE: knot t - 1's factor rows, stored during knot t
         auto store_knot = [&](int t, const double (&Hrow)[NT], double rdv, const double (&Mrow)[NX], double yv) {
             if (live && inT) {
-                double *o = fac + ((long long)t * NT + r) * C::ROW;
+                double *o = fac + (long long)t * NT * C::ROW + r;
     #pragma unroll
-                for (int c = 0; c < NT; ++c) o[c] = Hrow[c];
-                o[NT] = rdv;
+                for (int c = 0; c < NT; ++c) o[(c) * NT] = Hrow[c];
+                o[(NT) * NT] = rdv;
     #pragma unroll
-                for (int j = 0; j < NX; ++j) o[NT + 1 + j] = Mrow[j];
+                for (int j = 0; j < NX; ++j) o[(NT + 1 + j) * NT] = Mrow[j];
                 P.upd[b * (long long)T * NT + t * NT + r] = yv;        // y parked in the output
             }
         };
@@ -495,15 +554,23 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
     }
     // ---- backward sweep: upd_t = L_tt^-T (y_t - M_t upd_{t+1}[:NX]); knot t - 1's rows are loaded while knot t is
     // solved (a knot here is a memory round trip in front of nt group sums)
+    constexpr int BTS = G + 2, BPS = G * BTS + (G == 16 ? 16 : 0);         // the LDS tile of trsvT_bcast
+    __shared__ __attribute__((aligned(16))) double btile[(64 / G) * BPS];
+    double *brow = btile + (lane / G) * BPS + r;
+    const double *bcol = btile + (lane / G) * BPS + r * BTS;
+    if (!inT) {                          // lanes beyond the knot read their (unused) column: keep it finite
+#pragma unroll
+        for (int k = 0; k < NT; ++k) btile[(lane / G) * BPS + r * BTS + k] = 0.0;
+    }
     double xnext[1] = {0.0};
     double pL[NT], pM[NX], prd, pv;
     auto load_rows = [&](int t) {
-        const double *o = fac + ((long long)t * NT + (inT ? r : 0)) * C::ROW;
+        const double *o = fac + (long long)t * NT * C::ROW + (inT ? r : 0);
 #pragma unroll
-        for (int c = 0; c < NT; ++c) pL[c] = o[c];
-        prd = o[NT];
+        for (int c = 0; c < NT; ++c) pL[c] = o[(c) * NT];
+        prd = o[(NT) * NT];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) pM[j] = o[NT + 1 + j];
+        for (int j = 0; j < NX; ++j) pM[j] = o[(NT + 1 + j) * NT];
         pv = P.upd[b * (long long)T * NT + t * NT + (inT ? r : 0)];
     };
     load_rows(T - 1);
@@ -520,15 +587,21 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
 #pragma unroll
             for (int j = 0; j < NX; ++j) v[0] = fma(-M[j], Gr::rb(xnext[0], j), v[0]);
         }
-        trsvT_rows<G, NT>(L, rd, v, r);
+        v[0] = trsvT_bcast<G, NT, BTS>(L, rd[0], v[0], brow, bcol, r);
         if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = v[0];
         xnext[0] = inT ? v[0] : 0.0;
     }
+    BAND_STAMP(5);                  // backward sweep
+#ifdef DQP_BAND_STAMPS
+    if (P.stamps && lane == 0) for (int k_ = 0; k_ < 8; ++k_) P.stamps[blockIdx.x * 8 + k_] = stamp_acc[k_];
+#endif
     if (live && r == 0 && P.info) P.info[b] = bad;
 }
 
 // out = -(L L^T)^-1 rhs with the banded factor a forward launch left in `fac`
-// (NewtonAL.backward, al_utils.py:477-480)
+// (NewtonAL.backward, al_utils.py:477-480).  Both sweeps are chains of knots, each a memory round trip in front of a
+// short substitution: the next knot's rows are in flight while one is solved, and the substitutions are the
+// broadcast forms of the Newton kernel (unit_lower / trsv_unit forward, trsvT_bcast backward, M^T y from the LDS tile).
 template <class Map, int G>
 __global__ __launch_bounds__(64) void al_banded_solve_kernel(BandP P)
 {
@@ -543,48 +616,76 @@ __global__ __launch_bounds__(64) void al_banded_solve_kernel(BandP P)
     const int T = P.T;
     const bool inT = r < NT;
     const double *fac = P.fac + b * (long long)T * NT * C::ROW;
-    double Mprev[NX], yprev = 0.0;
+    const double *rhs = P.rhs + b * (long long)T * NT;
+    double *upd = P.upd + b * (long long)T * NT;
+    constexpr int TS = G + 2, PS = G * TS + (G == 16 ? 16 : 0);
+    __shared__ __attribute__((aligned(16))) double tile[(64 / G) * PS];
+    double *trow = tile + (lane / G) * PS + r;
+    const double *tcol = tile + (lane / G) * PS + r * TS;
 #pragma unroll
-    for (int j = 0; j < NX; ++j) Mprev[j] = 0.0;
+    for (int j = 0; j < G; ++j) trow[j * TS] = 0.0;
+
+    double pL[NT], pM[NX], prd, pv;
+    auto load_rows = [&](int t, const double *vec, double sign) {
+        const double *o = fac + (long long)t * NT * C::ROW + (inT ? r : 0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) pL[c] = o[(c) * NT];
+        prd = o[(NT) * NT];
+#pragma unroll
+        for (int j = 0; j < NX; ++j) pM[j] = o[(NT + 1 + j) * NT];
+        pv = sign * vec[t * NT + (inT ? r : 0)];
+    };
+    // ---- forward: y_t = L_tt^-1 (-rhs_t - M_{t-1}^T y_{t-1})
+    double Mt[G], yprev = 0.0;
+    load_rows(0, rhs, -1.0);
     for (int t = 0; t < T; ++t) {
-        const double *o = fac + ((long long)t * NT + (inT ? r : 0)) * C::ROW;
         double L[1][NT], rd[1], M[NX];
 #pragma unroll
-        for (int c = 0; c < NT; ++c) L[0][c] = inT ? o[c] : ((r == c) ? 1.0 : 0.0);
-        rd[0] = inT ? o[NT] : 1.0;
+        for (int c = 0; c < NT; ++c) L[0][c] = inT ? pL[c] : 0.0;
+        rd[0] = inT ? prd : 0.0;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) M[j] = inT ? o[NT + 1 + j] : 0.0;
-        double y[1] = {inT ? -P.rhs[b * (long long)T * NT + t * NT + (inT ? r : 0)] : 0.0};
+        for (int j = 0; j < NX; ++j) M[j] = inT ? pM[j] : 0.0;
+        double y = inT ? pv : 0.0;
+        if (t + 1 < T) load_rows(t + 1, rhs, -1.0);
         if (t > 0) {
+            double a = 0.0;
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
-                const double tot = Gr::sum(Mprev[i] * yprev);
-                if (r == i) y[0] -= tot;
-            }
+            for (int k = 0; k < NT; ++k) a = fma(Mt[k], Gr::rb(yprev, k), a);
+            y -= a;
         }
-        trsv_g<G, NT>(L, rd, y, r);
-        if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = y[0];
+        unit_lower<G, NT>(L, rd, r);
+        y = trsv_unit<G, NT>(L, y) * rd[0];
+        if (live && inT) upd[t * NT + r] = y;
+        yprev = inT ? y : 0.0;
+        // column r of M_t for the next knot (lanes beyond nx read the zero columns)
 #pragma unroll
-        for (int j = 0; j < NX; ++j) Mprev[j] = M[j];
-        yprev = inT ? y[0] : 0.0;
+        for (int j = 0; j < NX; ++j) trow[j * TS] = M[j];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < G; ++k) Mt[k] = tcol[k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    double xnext[1] = {0.0};
+    // ---- backward: out_t = L_tt^-T (y_t - M_t out_{t+1}[:nx])
+    double xnext = 0.0;
+    load_rows(T - 1, upd, 1.0);
     for (int t = T - 1; t >= 0; --t) {
-        const double *o = fac + ((long long)t * NT + (inT ? r : 0)) * C::ROW;
-        double L[1][NT], rd[1], M[NX];
+        double L[1][NT], M[NX];
 #pragma unroll
-        for (int c = 0; c < NT; ++c) L[0][c] = inT ? o[c] : 0.0;
-        rd[0] = inT ? o[NT] : 0.0;
+        for (int c = 0; c < NT; ++c) L[0][c] = inT ? pL[c] : 0.0;
+        const double rdv = inT ? prd : 0.0;
 #pragma unroll
-        for (int j = 0; j < NX; ++j) M[j] = inT ? o[NT + 1 + j] : 0.0;
-        double v[1] = {inT ? P.upd[b * (long long)T * NT + t * NT + (inT ? r : 0)] : 0.0};
+        for (int j = 0; j < NX; ++j) M[j] = inT ? pM[j] : 0.0;
+        double v = inT ? pv : 0.0;
+        if (t > 0) load_rows(t - 1, upd, 1.0);
         if (t < T - 1) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) v[0] = fma(-M[j], Gr::rb(xnext[0], j), v[0]);
+            for (int j = 0; j < NX; ++j) v = fma(-M[j], Gr::rb(xnext, j), v);
         }
-        trsvT_rows<G, NT>(L, rd, v, r);
-        if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = v[0];
-        xnext[0] = inT ? v[0] : 0.0;
+        v = trsvT_bcast<G, NT, TS>(L, rdv, v, trow, tcol, r);
+        if (live && inT) upd[t * NT + r] = v;
+        xnext = inT ? v : 0.0;
     }
 }
 
@@ -612,8 +713,12 @@ inline bool narrow(int B)
     }
     return (B + 3) / 4 > g_simds;
 }
-template <class Map> int run_newton(const BandP &P, void *stream)
+template <class Map> int run_newton(const BandP &P_, void *stream)
 {
+    BandP P = P_;
+#ifdef DQP_BAND_STAMPS
+    P.stamps = g_band_stamps;
+#endif
     if constexpr (half_row<Map>()) {
         if (narrow(P.B)) {
             DQP_LAUNCH((al_banded_newton_kernel<Map, 8>), dim3((P.B + 7) / 8), dim3(64), 0, (hipStream_t)stream, P);
@@ -661,6 +766,11 @@ int knot_doubles(int id, int n_, int m_)          // nt rows x (L row, 1/diag, M
 using namespace dqp::dyn;
 
 extern "C" {
+
+#ifdef DQP_BAND_STAMPS
+// instrumented build only: device buffer of 8 x uint64 per workgroup of the Newton kernel
+__attribute__((visibility("default"))) void dqp_debug_band_stamps(void *dev_ptr) { g_band_stamps = (unsigned long long *)dev_ptr; }
+#endif
 
 __attribute__((visibility("default"))) size_t dqp_al_banded_factor_bytes(const dqp_al_mpc_dims *d, int dyn_id)
 {
