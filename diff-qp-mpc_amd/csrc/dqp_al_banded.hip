@@ -254,15 +254,25 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
         const double *tcol = trs + (lane / G) * PS + r * TS;
     #pragma unroll
         for (int j = NX; j < G; ++j) trow[j * TS] = 0.0;
+        // the knot and its successor's state (uniform loads), fetched one knot ahead: vmcnt is in order on this ISA, so
+        // loads issued behind a knot's nt + 1 + nx factor stores wait for those stores too -- the next knot's are issued in
+        // front of them (they are the model's inputs: nothing else has to stay live for it)
+        double pz[NT], pxn1[NX];
+        auto load_state = [&](int t) {
+    #pragma unroll
+            for (int j = 0; j < NT; ++j) pz[j] = xu[t * NT + j];
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) pxn1[j] = (t < T - 1) ? xu[(t + 1) * NT + j] : 0.0;
+        };
+        load_state(0);
         for (int t = 0; t < T; ++t) {
-            // ---- the knot and its successor's state (uniform loads)
             double z[NT], xn1[NX];
     #pragma unroll
-            for (int j = 0; j < NT; ++j) z[j] = xu[t * NT + j];
+            for (int j = 0; j < NT; ++j) z[j] = pz[j];
             const bool dynrow = t < T - 1;
     #pragma unroll
-            for (int j = 0; j < NX; ++j) xn1[j] = dynrow ? xu[(t + 1) * NT + j] : 0.0;
-            BAND_STAMP(0);          // knot loads (and the previous knot's stores)
+            for (int j = 0; j < NX; ++j) xn1[j] = pxn1[j];
+            BAND_STAMP(0);          // knot loads
             // ---- column r of J_t = [df/dx df/du] by one forward-mode seed per lane
             double Jc[NX], mu[NX];
             if constexpr (is_given<Map>::value) {
@@ -355,6 +365,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
                 y[0] -= a;
             }
             // ---- keep the knot's factor rows (banded form), then turn the registers into the unit-triangular form
+            if (t + 1 < T) load_state(t + 1);
             double *o = fac + (long long)t * NT * C::ROW + r;
             if (live && inT) {
     #pragma unroll
