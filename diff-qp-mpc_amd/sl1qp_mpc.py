@@ -13,7 +13,7 @@ nineq variables: 90 at n 3 m 3 T 5, 120 at the pendulum's T 10 -- runs on the bl
 through DenseQPFunction, and the equality residual inside the iterations is the extended linear form
 A z - v + w - b (the reference passes the true-dynamics residual minus v plus w, sl1qp_mpc.py:344-364: identical for
 LinDx; for a nonlinear model this is the `linearised_residual` behaviour of qp_wrapper.MPC).  Parity of the clone is
-unpinned (nothing to run in the reference); the formulation is checked against the CPU oracle on the extended QP and
+unpinned (nothing to run in the reference); the formulation is checked against the CPU restatement (tests only) on the extended QP and
 against qp_wrapper.MPC in the exact-penalty regime (tests/test_gpu_big.py).
 """
 import torch
