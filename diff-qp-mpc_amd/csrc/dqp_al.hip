@@ -1142,7 +1142,7 @@ __attribute__((visibility("default"))) size_t dqp_al_newton_solve_bytes(const dq
 static int newton_solve_impl(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_steps, int32_t banded,
                              const double *x0, const double *Qdiag, const double *q, const double *lam, const double *rho,
                              const double *u_lower, const double *u_upper, double *xu, double *L, double *status,
-                             int32_t *fail, void *workspace, void *stream, bool clear_fail);
+                             int32_t *fail, void *workspace, void *stream, bool clear_fail, bool keep_factor = true);
 
 __attribute__((visibility("default"))) int
 dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_steps, int32_t banded,
@@ -1158,7 +1158,7 @@ dqp_al_newton_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_s
 static int newton_solve_impl(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t n_steps, int32_t banded,
                              const double *x0, const double *Qdiag, const double *q, const double *lam, const double *rho,
                              const double *u_lower, const double *u_upper, double *xu, double *L, double *status,
-                             int32_t *fail, void *workspace, void *stream, bool clear_fail)
+                             int32_t *fail, void *workspace, void *stream, bool clear_fail, bool keep_factor)
 {
     if (!d || d->nbatch < 0 || d->n_state <= 0 || d->n_ctrl <= 0 || d->T < 2 || n_steps < 1) return DQP_ERR_BAD_ARG;
     if (d->nbatch == 0) return DQP_OK;
@@ -1183,8 +1183,9 @@ static int newton_solve_impl(const dqp_al_mpc_dims *d, int dyn_id, double dt, in
         int rc0 = launch_ls(Lp, st);                                    // merit at the start
         if (rc0) return rc0;
         for (int it = 0; it < n_steps; ++it) {
-            int rc = dqp_al_banded_newton_step(d, dyn_id, dt, xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, upd, L,
-                                               info, stream);
+            // only the last step's factor is used afterwards (NewtonAL.backward, al_utils.py:477-480)
+            int rc = dqp::al_banded_newton_step_keep(d, dyn_id, dt, xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, upd, L,
+                                                     info, stream, (it == n_steps - 1 && keep_factor) ? 1 : 0);
             if (rc) return rc;
             LsAP Lc = {xu, upd, x0, Qdiag, q, lam, rho, u_lower, u_upper, merit, dt, B, n, m, T, 20, dyn_id,
                        xu, merit_cur, status, fail, info};
@@ -1293,7 +1294,7 @@ dqp_al_mpc_solve(const dqp_al_mpc_dims *d, int dyn_id, double dt, int32_t al_ite
     for (int i = 0; i < al_iter; ++i) {
         const double *lam = hist_lam + (long long)i * B * ncon, *rho = hist_rho + (long long)i * B;
         int rc = newton_solve_impl(d, dyn_id, dt, newton_steps, 1, x0, Qdiag, q, lam, rho, u_lower, u_upper, xu, factor,
-                                   status, fail + i, workspace, stream, false);
+                                   status, fail + i, workspace, stream, false, i == al_iter - 1);
         if (rc) return rc;
         OutP O = {xu, x0, lam, rho, Qdiag, q, u_lower, u_upper, hist_lam + (long long)(i + 1) * B * ncon,
                   hist_cost + (long long)(i + 1) * B, res_norm, dt, B, n, m, T, dyn_id, hist_rho + (long long)(i + 1) * B};

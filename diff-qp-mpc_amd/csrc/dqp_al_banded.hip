@@ -47,6 +47,8 @@ struct BandP {
     int32_t *info;      // (B): 0 or 1 + knot of the first non-positive pivot
     double dt;
     int B, T;
+    int keep;           // 0: the caller does not need this step's factor (an intermediate Newton step) -- kernels that hold the
+                        // factor on chip (LF below) then leave `fac` untouched; 1: write it
 #ifdef DQP_BAND_STAMPS
     unsigned long long *stamps;     // instrumented build (tools/stamps_band.py): 8 accumulated s_memtime phases per workgroup
 #endif
@@ -217,7 +219,13 @@ __device__ __forceinline__ double trsvT_bcast(const double (&L)[1][NT], double r
     return b * rdv;
 }
 
-template <class Map, int G>
+// LF ("LDS factor", short horizons of the 6- to 8-row models: config 5's cartpole-2 at T = 5): the factor rows never
+// leave the chip between the forward and the backward sweep -- element k of knot t of lane (group p, row r) at
+// lf[(t (ROW + 1) + k) NL + p nt + r], NL = groups x nt (the idle lanes of a group take no space) -- and go to `fac` only
+// when the caller keeps this step's factor (BandP.keep: the last Newton step of a solve, which NewtonAL.backward
+// uses).  At B = 65536 the factor round trip (3.9 KB written and read back per problem and step, against 1 KB of inputs)
+// was most of the kernel's HBM traffic, in phase over all wavefronts.
+template <class Map, int G, bool LF = false>
 __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
 {
     using C = BandCfg<Map>;
@@ -240,18 +248,23 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
 #pragma unroll
     for (int j = 0; j < NX; ++j) { Mprev[j] = 0.0; mu_prev[j] = 0.0; }
 
+    // the group's LDS tile (element (row, col) at [col TS + row]): the forward sweep's transposed copy of M_t, then the
+    // backward sweep's transposed L_tt.  TS = G + 2 doubles puts a group's 16-byte column reads on distinct bank quads; PS
+    // shifts neighbouring 16-lane groups by half the banks for the row-wise writes.
+    constexpr int TS = G + 2, PS = G * TS + (G == 16 ? 16 : 0);
+    __shared__ __attribute__((aligned(16))) double trs[(64 / G) * PS];
+    double *trow = trs + (lane / G) * PS + r;
+    const double *tcol = trs + (lane / G) * PS + r * TS;
     constexpr bool PRE = NT <= 8;        // small models: prefetched knot inputs, delayed factor stores (below)
+    static_assert(!LF || PRE, "the LDS-resident factor is for the small models");
+    extern __shared__ double lf_dyn[];
+    constexpr int NL = (64 / G) * NT, LROW = C::ROW + 1;
+    double *lf = lf_dyn + (lane / G) * NT + (inT ? r : 0);          // + (t LROW + k) NL
     BAND_STAMP_INIT;
     if constexpr (!PRE) {
         static_assert(G == 16, "the large-model sweep keeps one knot per DPP row");
-        // transposed copy of M_t (nt rows over the lanes, nx columns in registers): column j of group p at
-        // trs[p PS + j TS + row]; TS = 18 doubles puts the 16 lanes' 16-byte column reads on 16 distinct bank quads, PS
-        // shifts neighbouring groups by half the banks for the row-wise writes.  Columns nx .. 15 stay zero: lanes
-        // beyond nx read them and so subtract nothing.
-        constexpr int TS = 18, PS = 16 * TS + 16;
-        __shared__ __attribute__((aligned(16))) double trs[(64 / G) * PS];
-        double *trow = trs + (lane / G) * PS + r;
-        const double *tcol = trs + (lane / G) * PS + r * TS;
+        // transposed copy of M_t (nt rows over the lanes, nx columns in registers) in the tile: columns nx .. 15 stay zero,
+        // lanes beyond nx read them and so subtract nothing
     #pragma unroll
         for (int j = NX; j < G; ++j) trow[j * TS] = 0.0;
         // the knot and its successor's state (uniform loads), fetched one knot ahead: vmcnt is in order on this ISA, so
@@ -440,11 +453,6 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             }
         };
         if constexpr (PRE) load_knot(0);
-        // transposed copy of M_t, as in the large-model sweep, for groups of G lanes
-        constexpr int TS = G + 2, PS = G * TS + (G == 16 ? 16 : 0);
-        __shared__ __attribute__((aligned(16))) double trs[(64 / G) * PS];
-        double *trow = trs + (lane / G) * PS + r;
-        const double *tcol = trs + (lane / G) * PS + r * TS;
     #pragma unroll
         for (int j = NX; j < G; ++j) trow[j * TS] = 0.0;
 
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             const bool dynrow = t < T - 1;
             if constexpr (PRE) {
                 if (t + 1 < T) load_knot(t + 1);
-                if (t > 0) store_knot(t - 1, sH, srd, sM, sy);
+                if constexpr (!LF) { if (t > 0) store_knot(t - 1, sH, srd, sM, sy); }
             }
             // ---- column r of J_t = [df/dx df/du] by one forward-mode seed per lane
             double Jc[NX], mu[NX];
@@ -541,8 +549,16 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             }
             // ---- keep the knot's factor rows (banded form; written while the next knot computes), then the solves on the
             // unit-triangular form
+            if constexpr (LF) {
+                if (inT) {
     #pragma unroll
-            for (int c = 0; c < NT; ++c) sH[c] = H[0][c];
+                    for (int c = 0; c < NT; ++c) lf[(t * LROW + c) * NL] = H[0][c];
+                    lf[(t * LROW + NT) * NL] = rd[0];
+                }
+            } else {
+    #pragma unroll
+                for (int c = 0; c < NT; ++c) sH[c] = H[0][c];
+            }
             unit_lower<G, NT>(H, rd, r);
             const double rdm = inT ? rd[0] : 0.0, nrho_rd = -rho * rdm;
             y[0] = trsv_unit<G, NT>(H, y[0]) * rdm;
@@ -550,9 +566,17 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             double M[NX];
     #pragma unroll
             for (int j = 0; j < NX; ++j) M[j] = trsv_unit<G, NT>(H, Jc[j]) * nrho_rd;
+            if constexpr (LF) {
+                if (inT) {
     #pragma unroll
-            for (int j = 0; j < NX; ++j) sM[j] = M[j];
-            srd = rd[0]; sy = y[0];
+                    for (int j = 0; j < NX; ++j) lf[(t * LROW + NT + 1 + j) * NL] = M[j];
+                    lf[(t * LROW + C::ROW) * NL] = y[0];
+                }
+            } else {
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) sM[j] = M[j];
+                srd = rd[0]; sy = y[0];
+            }
     #pragma unroll
             for (int j = 0; j < NX; ++j) { Mprev[j] = M[j]; mu_prev[j] = mu[j]; }
             yprev[0] = inT ? y[0] : 0.0;
@@ -561,28 +585,29 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (PRE) store_knot(T - 1, sH, srd, sM, sy);
+        if constexpr (PRE && !LF) store_knot(T - 1, sH, srd, sM, sy);
     }
     // ---- backward sweep: upd_t = L_tt^-T (y_t - M_t upd_{t+1}[:NX]); knot t - 1's rows are loaded while knot t is
     // solved (a knot here is a memory round trip in front of nt group sums)
-    constexpr int BTS = G + 2, BPS = G * BTS + (G == 16 ? 16 : 0);         // the LDS tile of trsvT_bcast
-    __shared__ __attribute__((aligned(16))) double btile[(64 / G) * BPS];
-    double *brow = btile + (lane / G) * BPS + r;
-    const double *bcol = btile + (lane / G) * BPS + r * BTS;
-    if (!inT) {                          // lanes beyond the knot read their (unused) column: keep it finite
-#pragma unroll
-        for (int k = 0; k < NT; ++k) btile[(lane / G) * BPS + r * BTS + k] = 0.0;
-    }
     double xnext[1] = {0.0};
     double pL[NT], pM[NX], prd, pv;
     auto load_rows = [&](int t) {
-        const double *o = fac + (long long)t * NT * C::ROW + (inT ? r : 0);
+        if constexpr (LF) {
 #pragma unroll
-        for (int c = 0; c < NT; ++c) pL[c] = o[(c) * NT];
-        prd = o[(NT) * NT];
+            for (int c = 0; c < NT; ++c) pL[c] = lf[(t * LROW + c) * NL];
+            prd = lf[(t * LROW + NT) * NL];
 #pragma unroll
-        for (int j = 0; j < NX; ++j) pM[j] = o[(NT + 1 + j) * NT];
-        pv = P.upd[b * (long long)T * NT + t * NT + (inT ? r : 0)];
+            for (int j = 0; j < NX; ++j) pM[j] = lf[(t * LROW + NT + 1 + j) * NL];
+            pv = lf[(t * LROW + C::ROW) * NL];
+        } else {
+            const double *o = fac + (long long)t * NT * C::ROW + (inT ? r : 0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) pL[c] = o[(c) * NT];
+            prd = o[(NT) * NT];
+#pragma unroll
+            for (int j = 0; j < NX; ++j) pM[j] = o[(NT + 1 + j) * NT];
+            pv = P.upd[b * (long long)T * NT + t * NT + (inT ? r : 0)];
+        }
     };
     load_rows(T - 1);
     for (int t = T - 1; t >= 0; --t) {
@@ -598,9 +623,18 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
 #pragma unroll
             for (int j = 0; j < NX; ++j) v[0] = fma(-M[j], Gr::rb(xnext[0], j), v[0]);
         }
-        v[0] = trsvT_bcast<G, NT, BTS>(L, rd[0], v[0], brow, bcol, r);
+        v[0] = trsvT_bcast<G, NT, TS>(L, rd[0], v[0], trow, tcol, r);
         if (live && inT) P.upd[b * (long long)T * NT + t * NT + r] = v[0];
         xnext[0] = inT ? v[0] : 0.0;
+    }
+    if constexpr (LF) {
+        if (P.keep && live && inT) {
+            for (int t = 0; t < T; ++t) {
+                double *o = fac + (long long)t * NT * C::ROW + r;
+#pragma unroll
+                for (int k = 0; k < C::ROW; ++k) o[k * NT] = lf[(t * LROW + k) * NL];
+            }
+        }
     }
     BAND_STAMP(5);                  // backward sweep
 #ifdef DQP_BAND_STAMPS
@@ -732,6 +766,16 @@ template <class Map> int run_newton(const BandP &P_, void *stream)
 #endif
     if constexpr (half_row<Map>()) {
         if (narrow(P.B)) {
+            if constexpr (Map::NX + Map::NU >= 6) {
+                // the one-wavefront-per-SIMD half-row models: the factor stays in LDS where the horizon allows (four
+                // workgroups per CU next to their 5 KB tiles)
+                using C = BandCfg<Map>;
+                const size_t bytes = (size_t)P.T * (C::ROW + 1) * 8 * C::NT * sizeof(double);
+                if (bytes <= 34 * 1024) {
+                    DQP_LAUNCH((al_banded_newton_kernel<Map, 8, true>), dim3((P.B + 7) / 8), dim3(64), bytes, (hipStream_t)stream, P);
+                    return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
+                }
+            }
             DQP_LAUNCH((al_banded_newton_kernel<Map, 8>), dim3((P.B + 7) / 8), dim3(64), 0, (hipStream_t)stream, P);
             return hipGetLastError() == hipSuccess ? DQP_OK : DQP_ERR_LAUNCH;
         }
@@ -790,11 +834,14 @@ __attribute__((visibility("default"))) size_t dqp_al_banded_factor_bytes(const d
     return (size_t)d->nbatch * d->T * kd * sizeof(double);
 }
 
-__attribute__((visibility("default"))) int
-dqp_al_banded_newton_step(const dqp_al_mpc_dims *d, int dyn_id, double dt, const double *xu, const double *x0,
-                          const double *Qdiag, const double *q, const double *lam, const double *rho,
-                          const double *u_lower, const double *u_upper, double *update, void *factor,
-                          int32_t *info, void *stream)
+}  // extern "C"
+
+// dqp_al_banded_newton_step with the caller saying whether it needs this step's factor afterwards (the Newton loop of
+// dqp_al.hip keeps the last step's only)
+int dqp::al_banded_newton_step_keep(const dqp_al_mpc_dims *d, int dyn_id, double dt, const double *xu, const double *x0,
+                                    const double *Qdiag, const double *q, const double *lam, const double *rho,
+                                    const double *u_lower, const double *u_upper, double *update, void *factor,
+                                    int32_t *info, void *stream, int keep)
 {
     if (!d || d->nbatch < 0 || d->T < 2) return DQP_ERR_BAD_ARG;
     int32_t n = 0, m = 0;
@@ -802,7 +849,7 @@ dqp_al_banded_newton_step(const dqp_al_mpc_dims *d, int dyn_id, double dt, const
     if (d->nbatch == 0) return DQP_OK;
     if (!xu || !x0 || !Qdiag || !q || !lam || !rho || !u_lower || !u_upper || !update || !factor) return DQP_ERR_BAD_ARG;
     BandP P = {xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, nullptr, nullptr, nullptr, nullptr, update, (double *)factor,
-               info, dt, d->nbatch, d->T};
+               info, dt, d->nbatch, d->T, keep};
     switch (dyn_id) {
     case DQP_DYN_PENDULUM1L: return run_newton<Robot<Pendulum1l>>(P, stream);
     case DQP_DYN_CARTPOLE1L: return run_newton<Robot<Cartpole1l>>(P, stream);
@@ -811,6 +858,18 @@ dqp_al_banded_newton_step(const dqp_al_mpc_dims *d, int dyn_id, double dt, const
     case DQP_DYN_REXQUADROTOR: return run_newton<RexQuadrotor>(P, stream);
     default: return run_newton<PendulumDx>(P, stream);
     }
+}
+
+extern "C" {
+
+__attribute__((visibility("default"))) int
+dqp_al_banded_newton_step(const dqp_al_mpc_dims *d, int dyn_id, double dt, const double *xu, const double *x0,
+                          const double *Qdiag, const double *q, const double *lam, const double *rho,
+                          const double *u_lower, const double *u_upper, double *update, void *factor,
+                          int32_t *info, void *stream)
+{
+    return dqp::al_banded_newton_step_keep(d, dyn_id, dt, xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, update, factor, info,
+                                           stream, 1);
 }
 
 __attribute__((visibility("default"))) int
@@ -855,7 +914,7 @@ dqp_al_banded_newton_step_jac(const dqp_al_mpc_dims *d, const double *xu, const 
     if (!xu || !x0 || !Qdiag || !q || !lam || !rho || !u_lower || !u_upper || !x_next || !Jx || !Ju || !update || !factor)
         return DQP_ERR_BAD_ARG;
     BandP P = {xu, x0, Qdiag, q, lam, rho, u_lower, u_upper, nullptr, x_next, Jx, Ju, update, (double *)factor, info, 0.0,
-               d->nbatch, d->T};
+               d->nbatch, d->T, 1};
 #define X(a, b) if (d->n_state == a && d->n_ctrl == b) return run_newton<Given<a, b>>(P, stream);
     DQP_BAND_SIZES
 #undef X

@@ -121,6 +121,12 @@ long long big_workspace_doubles(int N, int M, int E);
 bool big_fits(int N, int M, int E);         // the solver's vectors fit the LDS of a CU
 int big_forward(const KParams &P, void *stream);
 int big_backward(const KParams &P, void *stream);
+
+// dqp_al_banded.hip: dqp_al_banded_newton_step with `keep` = does the caller use this step's factor afterwards
+int al_banded_newton_step_keep(const dqp_al_mpc_dims *d, int dyn_id, double dt, const double *xu, const double *x0,
+                               const double *Qdiag, const double *q, const double *lam, const double *rho,
+                               const double *u_lower, const double *u_upper, double *update, void *factor, int32_t *info,
+                               void *stream, int keep);
 // backward restarted from the context r16n_forward left in P.workspace (DQP_FLAG_BACKWARD_CTX)
 int r16n_backward(const KParams &P, void *stream);
 
