@@ -344,9 +344,15 @@ class PendulumMPC(Workload):
         lo, hi = torch.tensor([-2.0], **f64), torch.tensor([2.0], **f64)
         self.mpc = qp_wrapper.MPC(n, m, T, u_lower=lo, u_upper=hi, n_batch=B, verbose=-1, single_qp_solve=True)
         self.u = None
+        self.graphed = None
+        if getattr(args, "graph", False):      # the call and its backward as two hipGraphs (qp_wrapper.GraphedMPC)
+            self.graphed = qp_wrapper.graphed_mpc(self.mpc, (self.x0, self.C, self.c), lambda: (self.dyn, self.dyn.jac))
 
     def step(self, gather=None):
-        x, u = self.mpc(self.x0, self.qp_wrapper.QuadCost(self.C, self.c), self.dyn, self.dyn.jac)
+        if self.graphed is not None:
+            x, u = self.graphed(self.x0, self.C, self.c)
+        else:
+            x, u = self.mpc(self.x0, self.qp_wrapper.QuadCost(self.C, self.c), self.dyn, self.dyn.jac)
         self.u = u.detach().transpose(0, 1).contiguous()
         work = gather(self.u) if gather else None
         self.C.grad = self.c.grad = None
@@ -367,7 +373,8 @@ class PendulumMPC(Workload):
     def describe(self, world):
         return {"workload": "BASELINE configs[1]: qp_wrapper.MPC, PendulumDx (n 3, m 1), T 10, single-QP call, x0 as "
                             "il_env_nonconvex.py:62-65; stage-wise PDIPM with the true-dynamics residual + line search + "
-                            "backward; B=1024/GPU", "global_batch": world * self.B, "n_state": 3, "n_ctrl": 1, "T": 10,
+                            "backward; B=1024/GPU" + (", replayed as hipGraphs" if self.graphed else ""),
+                "global_batch": world * self.B, "n_state": 3, "n_ctrl": 1, "T": 10,
                 "parallelism": "replicas x%d" % world}
 
     def extras(self):

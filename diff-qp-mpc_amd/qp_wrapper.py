@@ -493,6 +493,8 @@ class MPC(Module):
         differentiable step from that trajectory."""
         keep_x = keep_u = keep_cost = None
         stalls = 0          # the reference never increments this counter either (qp_wrapper.py:356-380)
+        if getattr(self, "capturable", False):
+            return self._solve_nonlin_capturable(x, u, dx, dx_jac, x0, cost)
         with torch.no_grad():
             for _ in range(self.qp_iter):
                 u_before = u
@@ -509,6 +511,31 @@ class MPC(Module):
                     keep_cost = torch.where(better, cost_now, keep_cost)
                 if (u - u_before).norm() < self.eps or stalls > self.not_improved_lim:
                     break
+        return self._damped_step(keep_x, keep_u, dx, dx_jac, x0, cost)
+
+    def _solve_nonlin_capturable(self, x, u, dx, dx_jac, x0, cost):
+        """solve_nonlin without its host test (the `break` on |u - u_before| < eps, qp_wrapper.py:392): every one of the
+        qp_iter rounds is enqueued, and a device flag set by that test freezes (x, u, best trajectory) for the rounds
+        the reference would not have run -- same values, no synchronisation, so the whole call can sit in a hipGraph."""
+        keep_x = keep_u = keep_cost = None
+        done = torch.zeros((), dtype=torch.bool, device=x0.device)
+        with torch.no_grad():
+            for _ in range(self.qp_iter):
+                step_x, step_u, _ = self.single_qp(x, u, dx, dx_jac, x0, cost, need_cost=False)
+                x_new, u_new, _, cost_now = self.line_search(x, u, step_x, step_u, dx, x0, cost)
+                if keep_cost is None:
+                    new_x, new_u, new_cost = x_new, u_new, cost_now
+                else:
+                    better = cost_now <= keep_cost + self.best_cost_eps
+                    sel = better[None, :, None]
+                    new_x, new_u = torch.where(sel, x_new, keep_x), torch.where(sel, u_new, keep_u)
+                    new_cost = torch.where(better, cost_now, keep_cost)
+                    new_x, new_u = torch.where(done, keep_x, new_x), torch.where(done, keep_u, new_u)
+                    new_cost = torch.where(done, keep_cost, new_cost)
+                stop = (u_new - u).norm() < self.eps
+                x, u = torch.where(done, x, x_new), torch.where(done, u, u_new)
+                keep_x, keep_u, keep_cost = new_x, new_u, new_cost
+                done = done | stop
         return self._damped_step(keep_x, keep_u, dx, dx_jac, x0, cost)
 
     def single_qp_ls(self, x, u, dx, dx_jac, x0, cost):
@@ -693,7 +720,7 @@ class _GraphReplay(Function):
 
 
 class GraphedMPC:
-    """`mpc` (single_qp_solve) captured in two hipGraphs -- forward, and backward through the solver's
+    """`mpc` (single-QP or SQP mode) captured in two hipGraphs -- forward, and backward through the solver's
     implicit derivative -- sharing one memory pool.  The C-ABI entry points only enqueue on the
     current stream, allocate nothing and never synchronise, so a call is two graph launches instead
     of ~100 Python-dispatched ones.  Shapes, dtypes and the batch size are frozen at capture; inputs
@@ -701,7 +728,7 @@ class GraphedMPC:
 
     def __init__(self, mpc, sample_inputs, dx_factory=None, warmup=3):
         if not mpc.single_qp_solve:
-            raise NotImplementedError("SQP mode keeps a host test per round (qp_wrapper.py:392): not capturable")
+            mpc.capturable = True       # SQP: the rounds' stopping test moves onto the device (_solve_nonlin_capturable)
         self.mpc, self.dx_factory = mpc, dx_factory
         self.static_inputs = tuple(t.detach().clone().requires_grad_(t.requires_grad) for t in sample_inputs)
         side = torch.cuda.Stream()

@@ -320,10 +320,12 @@ def test_fused_line_search_equals_torch_path(kind):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-10, atol=1e-10, err_msg=k)
 
 
+@pytest.mark.parametrize("sqp", [False, True])
 @pytest.mark.parametrize("kind", ["lindx", "pendulum_dx"])
-def test_mpc_call_captured_in_hipgraphs(kind):
-    """qp_wrapper.MPC (single-QP mode) replayed from two hipGraphs (forward; backward through the
-    solver) gives bitwise the eager results on the capture inputs and follows new inputs."""
+def test_mpc_call_captured_in_hipgraphs(kind, sqp):
+    """qp_wrapper.MPC (single-QP mode, and SQP mode with qp_iter 3 -- the stopping test of the rounds on the device
+    instead of the host, qp_wrapper.py:392) replayed from two hipGraphs (forward; backward through the solver) gives
+    bitwise the eager results on the capture inputs and follows new inputs."""
     from diff_qp_mpc_amd import qp_wrapper
     from diff_qp_mpc_amd.dynamics import DeviceDynamics
     B, T = 64, 5
@@ -349,14 +351,15 @@ def test_mpc_call_captured_in_hipgraphs(kind):
         return x0.requires_grad_(), c.requires_grad_()
 
     one = torch.full((m,), lim, dtype=torch.float64, device="cuda")
-    mpc = qp_wrapper.MPC(n, m, T, u_lower=-one, u_upper=one, n_batch=B, verbose=-1, single_qp_solve=True,
-                         max_linesearch_iter=5)
+    make = lambda: qp_wrapper.MPC(n, m, T, u_lower=-one, u_upper=one, n_batch=B, verbose=-1, single_qp_solve=not sqp,
+                                  qp_iter=3, max_linesearch_iter=5, eps=1e-3)
+    mpc, mpc_eager = make(), make()         # the eager twin keeps the host test
 
     def eager(x0, c):
         if factory is None:
-            return mpc(x0, qp_wrapper.QuadCost(C, c), qp_wrapper.LinDx(*extra), None)
+            return mpc_eager(x0, qp_wrapper.QuadCost(C, c), qp_wrapper.LinDx(*extra), None)
         d, j = factory()
-        return mpc(x0, qp_wrapper.QuadCost(C, c), d, j)
+        return mpc_eager(x0, qp_wrapper.QuadCost(C, c), d, j)
 
     x0a, ca = inputs(2)
     sample = (x0a, C, ca) + extra
