@@ -462,8 +462,9 @@ int dqp_al_mpc_solve(const dqp_al_mpc_dims *dims, int dyn_id, double dt, int32_t
  * diag(Q) + rho Jc^T Jc is block tridiagonal in the knots, so linearisation, gradient, block Cholesky
  * and the solve run as ONE launch with every knot in registers (4 problems per wavefront), O(T (n+m)^3)
  * work, no Jacobian or Hessian in HBM.  `factor` (dqp_al_banded_factor_bytes) receives the banded
- * Cholesky factor -- per knot the rows of L_tt, 1/diag(L_tt) and L_{t+1,t}^T -- which
- * dqp_al_banded_solve applies for NewtonAL.backward (out = -(L L^T)^-1 rhs, al_utils.py:477-480).
+ * Cholesky factor -- per knot L_tt, 1/diag(L_tt) and L_{t+1,t}^T, in a layout private to the library (element-major
+ * over the knot's lanes) -- which dqp_al_banded_solve applies for NewtonAL.backward (out = -(L L^T)^-1 rhs,
+ * al_utils.py:477-480).  dqp_al_newton_solve / dqp_al_mpc_solve leave the factor of their LAST Newton step in it.
  * info (B): 0, or 1 + the knot at which a pivot was not positive.
  */
 size_t dqp_al_banded_factor_bytes(const dqp_al_mpc_dims *dims, int dyn_id);
