@@ -27,6 +27,7 @@ algorithm -- timed on this host on a bounded sample of the same workload; N = 1 
 """
 import argparse
 import ctypes
+import gc
 import json
 import os
 import socket
@@ -657,6 +658,8 @@ def main(argv=None):
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", type=int, default=1, choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run (config 1, one GPU): do not append the short runs of configs 2-5 (`other_configs`)")
     ap.add_argument("--batch", type=int, default=None, help="configs 3 and 5: another batch size (per GPU for 3, global for 5)")
     ap.add_argument("--robot", default=None, help="config 3: another registered model (cartpole2l, pendulum_euler, ...)")
     ap.add_argument("--T", type=int, default=None, help="config 3: another horizon")
@@ -735,6 +738,7 @@ def main(argv=None):
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    gc.collect(); gc.disable()          # no collector pauses inside the timed region (as timeit)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         wl.step(gather)
@@ -742,6 +746,7 @@ def main(argv=None):
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -750,7 +755,7 @@ def main(argv=None):
     # per-kernel times of the same step, HIP events on the launch stream (the library's own trace)
     tsteps = max(1, min(args.steps, 20))
     graphed, wl.graphed = getattr(wl, "graphed", None), None       # graph replays launch nothing through the library: trace the eager step
-    with _lib.trace(200000) as tr:
+    with _lib.trace(20000) as tr:          # (a step is at most ~150 library launches; the event pool is per slot)
         for _ in range(tsteps):
             wl.step(None)
         torch.cuda.synchronize()
@@ -809,6 +814,41 @@ def main(argv=None):
             "ms_per_step": e2 / args.steps * 1e3, "pdipm_iters_mean": float(wl2.info[:, 1].float().mean()),
             "max_abs_dzhat_vs_headline": float((wl2.zhat - zhat_head).abs().max()),
             "note": "float-tolerance parity only (include/dqp.h); every problem stops on its own"}
+
+    if args.config == 1 and world == 1 and not args.no_other_configs and args.batch is None:
+        # the other BASELINE configurations, each a short timed run of the same kind (warm-up, K steps between
+        # synchronisations, the library's trace for the dominant kernel): in the default line so that whoever runs
+        # `python bench.py` has all five on record; `--config C` gives a configuration its full line
+        out["other_configs"] = {}
+        for c in (2, 3, 4, 5):
+            try:
+                k_steps, k_warm = DEFAULT_STEPS[c]
+                k_warm = max(k_warm, 5)
+                w = WORKLOADS[c](torch, dev, rank, world, args)
+                for _ in range(k_warm):
+                    w.step(None)
+                torch.cuda.synchronize()
+                gc.collect(); gc.disable()      # (as timeit does: a generation-2 collection over this process's heap -- the
+                t0 = time.perf_counter()        # trace records of the runs before -- is a 45 ms pause in a 1.5 ms step)
+                for _ in range(k_steps):
+                    w.step(None)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                gc.enable()
+                with _lib.trace(2000) as tr:
+                    w.step(None)
+                    torch.cuda.synchronize()
+                kk = {short_kernel(k): (cnt, ms) for k, (cnt, ms) in tr.by_kernel().items()}
+                dom = max(kk, key=lambda k: kk[k][0] * kk[k][1])
+                out["other_configs"][str(c)] = {
+                    "metric": w.metric, "value": w.units * k_steps / el, "unit": w.unit, "steps": k_steps, "warmup": k_warm,
+                    "ms_per_step": el / k_steps * 1e3, "scaling": w.scaling, "dominant_kernel": dom,
+                    "dominant_kernel_launches_per_step": kk[dom][0], "dominant_kernel_avg_ms": kk[dom][1],
+                    "kernel_ms_per_step": sum(cnt * ms for cnt, ms in kk.values())}
+                del w
+                torch.cuda.empty_cache()
+            except Exception as e:            # a failing side run must not cost the headline line
+                out["other_configs"][str(c)] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:     # the CPU baseline is an N=1, rank-0 figure
