@@ -23,7 +23,8 @@ config 5.  Timing: W warm-up steps, then exactly K steps between barrier + synch
 Rank 0 prints ONE JSON line with `roofline` (the library kernel with the largest share of the step, timed live with
 HIP events on its launch stream by the library's own trace, dqp_trace_begin / dqp_trace_end; algorithmic bytes as
 DESIGN.md section 4 defines them per kernel) and `cpu_baseline` (the oracle -- a CPU port of the reference's
-algorithm -- timed on this host on a bounded sample of the same workload; N = 1 only).
+algorithm -- timed on this host on a bounded sample of the same workload; N = 1 only).  The default run (config 1,
+one GPU) also appends `other_configs`: a short timed run of each of configs 2-5 (--no-other-configs skips them).
 """
 import argparse
 import ctypes
