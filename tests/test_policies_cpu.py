@@ -71,3 +71,23 @@ def test_non_mlp_layers_raise_with_the_reason():
     a = argparse.Namespace(T=5, nq=1, hdim=16, layer_type="gcn", deq_out_type=1)
     with pytest.raises(NotImplementedError, match="gcn"):
         policies.DEQLayer(a, env)
+
+
+def test_sliced_linear_matches_linear_on_cpu():
+    """policies.SlicedLinear (the DEQLayer linears' weight gradient as a batched product over row slices): same forward and
+    the same three gradients as torch.nn.functional.linear, here in float64 on the CPU where the sums agree to round-off."""
+    torch.manual_seed(0)
+    for rows in (1024, 1536, 1000):                 # 2 slices of 512, 1 slice (1536 = 3 x 512 has no even split), odd
+        x = torch.randn(rows, 7, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(5, 7, dtype=torch.float64, requires_grad=True)
+        b = torch.randn(5, dtype=torch.float64, requires_grad=True)
+        g = torch.randn(rows, 5, dtype=torch.float64)
+        y0 = torch.nn.functional.linear(x, w, b)
+        want = torch.autograd.grad(y0, (x, w, b), g)
+        y1 = policies.SlicedLinear.apply(x, w, b)
+        got = torch.autograd.grad(y1, (x, w, b), g)
+        torch.testing.assert_close(y1, y0, rtol=0, atol=0)
+        for a, c in zip(got, want):
+            torch.testing.assert_close(a, c, rtol=1e-12, atol=1e-12)
+        y2 = policies.SlicedLinear.apply(x, w, None)        # no bias
+        torch.testing.assert_close(torch.autograd.grad(y2, w, g)[0], want[1], rtol=1e-12, atol=1e-12)
