@@ -415,14 +415,36 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
         const int rr = inT ? r : 0, rx = r < NX ? r : 0, iu = (inT && r >= NX) ? r - NX : 0;
         double x0r = 0.0, lam_first = 0.0, uur = 0.0, ulr = 0.0;        // knot-independent: loaded once where registers allow
         if constexpr (PRE) { x0r = x0[rx]; lam_first = lam[(T - 1) * NX + rx]; uur = P.uu[iu]; ulr = P.ul[iu]; }
+        // KB ("knot batching"): a group of G lanes has G / nt times the lanes one knot's nt forward-mode seeds need -- three
+        // knots' worth at cartpole-1 on a 16-lane row, five at the pendulums -- and the model evaluation is the larger part
+        // of a knot (1.1 k of 1.8 k instructions at cartpole-1).  Every KP knots the lanes evaluate the model of KP knots at
+        // once (lane r: knot t + r / nt, seed r % nt) and leave the Jacobian columns and the residuals in LDS; the sweep
+        // then takes each knot's column from there.
+        constexpr int KP = (PRE && !is_given<Map>::value) ? G / NT : 1;
+        constexpr bool KB = KP >= 2;
+        constexpr int JBK = NX * (NT + 1);                     // per knot: NX rows of [J[j][0..nt-1], res_j]
+        __shared__ double jbuf[KB ? (64 / G) * KP * JBK : 1];
+        double *jb = jbuf + (KB ? (lane / G) * KP * JBK : 0);
+        const int kk = KB ? r / NT : 0, kr = KB ? r - kk * NT : r;       // this lane's knot in the batch / its seed
+        const bool kact = KB && r < KP * NT;
+        double pzk[NT], pxnk[NX];                                        // the lane's model inputs of the NEXT batch
+        auto load_batch = [&](int t0) {
+            const int tk = t0 + kk, tc = (kact && tk < T) ? tk : 0, tn = (kact && tk < T - 1) ? tk + 1 : 0;
+    #pragma unroll
+            for (int j = 0; j < NT; ++j) pzk[j] = xu[tc * NT + j];
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) pxnk[j] = xu[tn * NT + j];
+        };
         double pz[NT], pxn1[NX], plam[NX], pfx[NX], pcol[NX], pzr, pqd, pq, plu, pll;
         auto load_knot = [&](int t) {
             const bool dynrow = t < T - 1;
+            if constexpr (!KB) {
     #pragma unroll
-            for (int j = 0; j < NT; ++j) pz[j] = xu[t * NT + j];
+                for (int j = 0; j < NT; ++j) pz[j] = xu[t * NT + j];
+            }
     #pragma unroll
             for (int j = 0; j < NX; ++j) {
-                pxn1[j] = dynrow ? xu[(t + 1) * NT + j] : 0.0;
+                if constexpr (!KB) pxn1[j] = dynrow ? xu[(t + 1) * NT + j] : 0.0;
                 plam[j] = dynrow ? lam[t * NX + j] : 0.0;
             }
             if constexpr (is_given<Map>::value) {
@@ -453,6 +475,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             }
         };
         if constexpr (PRE) load_knot(0);
+        if constexpr (KB) load_batch(0);
     #pragma unroll
         for (int j = NX; j < G; ++j) trow[j * TS] = 0.0;
 
@@ -463,10 +486,14 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             }
             // ---- the knot and its successor's state
             double z[NT], xn1[NX], lamt[NX], fxv[NX], colv[NX];
+            if constexpr (!KB) {
     #pragma unroll
-            for (int j = 0; j < NT; ++j) z[j] = pz[j];
+                for (int j = 0; j < NT; ++j) z[j] = pz[j];
     #pragma unroll
-            for (int j = 0; j < NX; ++j) { xn1[j] = pxn1[j]; lamt[j] = plam[j]; fxv[j] = pfx[j]; colv[j] = pcol[j]; }
+                for (int j = 0; j < NX; ++j) xn1[j] = pxn1[j];
+            }
+    #pragma unroll
+            for (int j = 0; j < NX; ++j) { lamt[j] = plam[j]; fxv[j] = pfx[j]; colv[j] = pcol[j]; }
             const double zr = pzr, qdr = pqd, qr = pq, lup = plu, llo = pll;
             const bool dynrow = t < T - 1;
             if constexpr (PRE) {
@@ -481,6 +508,32 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
                     Jc[j] = (dynrow && inT) ? colv[j] : 0.0;
                     const double res = dynrow ? xn1[j] - fxv[j] : 0.0;
                     mu[j] = dynrow ? lamt[j] + rho * res : 0.0;
+                }
+            } else if constexpr (KB) {
+                if (t % KP == 0) {            // the model of knots t .. t + KP - 1, one seed of one knot per lane
+                    Dual<1> xs[NX], us[NU], out[NX];
+    #pragma unroll
+                    for (int j = 0; j < NX; ++j) { xs[j] = Dual<1>(pzk[j]); xs[j].d[0] = (kr == j) ? 1.0 : 0.0; }
+    #pragma unroll
+                    for (int j = 0; j < NU; ++j) { us[j] = Dual<1>(pzk[NX + j]); us[j].d[0] = (kr == NX + j) ? 1.0 : 0.0; }
+                    Map::template step<Dual<1>>(xs, us, P.dt, out);
+                    const bool dk = kact && t + kk < T - 1;           // the lane's knot has a dynamics row
+                    if (kact) {
+    #pragma unroll
+                        for (int j = 0; j < NX; ++j) {
+                            jb[kk * JBK + j * (NT + 1) + kr] = dk ? out[j].d[0] : 0.0;
+                            if (kr == 0) jb[kk * JBK + j * (NT + 1) + NT] = dk ? pxnk[j] - out[j].v : 0.0;   // x_{t+1} - f(x_t, u_t)
+                        }
+                    }
+                    if (t + KP < T) load_batch(t + KP);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                const int kt = t % KP;
+    #pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    Jc[j] = inT ? jb[kt * JBK + j * (NT + 1) + (inT ? r : 0)] : 0.0;
+                    mu[j] = dynrow ? lamt[j] + rho * jb[kt * JBK + j * (NT + 1) + NT] : 0.0;
                 }
             } else {
                 Dual<1> xs[NX], us[NU], out[NX];
