@@ -413,14 +413,13 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
         // computes and write knot t's factor rows while knot t + 1 computes: a knot was one exposed memory round trip
         // in front of ~2.5 k instructions, and its stores were in the way of the next knot's loads (vmcnt is in order).
         const int rr = inT ? r : 0, rx = r < NX ? r : 0, iu = (inT && r >= NX) ? r - NX : 0;
-        double x0r = 0.0, lam_first = 0.0, uur = 0.0, ulr = 0.0;        // knot-independent: loaded once where registers allow
-        if constexpr (PRE) { x0r = x0[rx]; lam_first = lam[(T - 1) * NX + rx]; uur = P.uu[iu]; ulr = P.ul[iu]; }
+        const double x0r = x0[rx], lam_first = lam[(T - 1) * NX + rx], uur = P.uu[iu], ulr = P.ul[iu];       // knot-independent
         // KB ("knot batching"): a group of G lanes has G / nt times the lanes one knot's nt forward-mode seeds need -- three
         // knots' worth at cartpole-1 on a 16-lane row, five at the pendulums -- and the model evaluation is the larger part
         // of a knot (1.1 k of 1.8 k instructions at cartpole-1).  Every KP knots the lanes evaluate the model of KP knots at
         // once (lane r: knot t + r / nt, seed r % nt) and leave the Jacobian columns and the residuals in LDS; the sweep
         // then takes each knot's column from there.
-        constexpr int KP = (PRE && !is_given<Map>::value) ? G / NT : 1;
+        constexpr int KP = !is_given<Map>::value ? G / NT : 1;
         constexpr bool KB = KP >= 2;
         constexpr int JBK = NX * (NT + 1);                     // per knot: NX rows of [J[j][0..nt-1], res_j]
         __shared__ double jbuf[KB ? (64 / G) * KP * JBK : 1];
@@ -462,7 +461,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             const int row = neq + t * 2 * NU + iu;
             plu = lam[row]; pll = lam[row + NU];
         };
-        double sH[NT], sM[NX], srd = 0.0, sy = 0.0;              // PRE: knot t - 1's factor rows, stored during knot t
+        double sH[NT], sM[NX], srd = 0.0, sy = 0.0;              // knot t - 1's factor rows, stored during knot t
         auto store_knot = [&](int t, const double (&Hrow)[NT], double rdv, const double (&Mrow)[NX], double yv) {
             if (live && inT) {
                 double *o = fac + (long long)t * NT * C::ROW + r;
@@ -474,16 +473,12 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
                 P.upd[b * (long long)T * NT + t * NT + r] = yv;        // y parked in the output
             }
         };
-        if constexpr (PRE) load_knot(0);
+        load_knot(0);
         if constexpr (KB) load_batch(0);
     #pragma unroll
         for (int j = NX; j < G; ++j) trow[j * TS] = 0.0;
 
         for (int t = 0; t < T; ++t) {
-            if constexpr (!PRE) {
-                load_knot(t);
-                x0r = x0[rx]; lam_first = lam[(T - 1) * NX + rx]; uur = P.uu[iu]; ulr = P.ul[iu];
-            }
             // ---- the knot and its successor's state
             double z[NT], xn1[NX], lamt[NX], fxv[NX], colv[NX];
             if constexpr (!KB) {
@@ -496,10 +491,8 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             for (int j = 0; j < NX; ++j) { lamt[j] = plam[j]; fxv[j] = pfx[j]; colv[j] = pcol[j]; }
             const double zr = pzr, qdr = pqd, qr = pq, lup = plu, llo = pll;
             const bool dynrow = t < T - 1;
-            if constexpr (PRE) {
-                if (t + 1 < T) load_knot(t + 1);
-                if constexpr (!LF) { if (t > 0) store_knot(t - 1, sH, srd, sM, sy); }
-            }
+            if (t + 1 < T) load_knot(t + 1);
+            if constexpr (!LF) { if (t > 0) store_knot(t - 1, sH, srd, sM, sy); }
             // ---- column r of J_t = [df/dx df/du] by one forward-mode seed per lane
             double Jc[NX], mu[NX];
             if constexpr (is_given<Map>::value) {
@@ -638,7 +631,7 @@ __global__ __launch_bounds__(64) void al_banded_newton_kernel(BandP P)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         }
-        if constexpr (PRE && !LF) store_knot(T - 1, sH, srd, sM, sy);
+        if constexpr (!LF) store_knot(T - 1, sH, srd, sM, sy);
     }
     // ---- backward sweep: upd_t = L_tt^-T (y_t - M_t upd_{t+1}[:NX]); knot t - 1's rows are loaded while knot t is
     // solved (a knot here is a memory round trip in front of nt group sums)
