@@ -20,6 +20,12 @@
 // the lanes as in the QP kernels (dqp_r16_prims.h).  The factor is kept in its banded form
 // (per knot: L_tt rows, 1/diag, L_{t+1,t}^T rows) for the backward pass (al_utils.py:477-480).
 //
+// Variants of the sweep (all the same arithmetic up to summation order): the substitutions run on the unit-triangular
+// form (unit_lower / trsv_unit: one broadcast + one fma per step), M^T M and M^T y come from an LDS-transposed copy of M,
+// L^-T is applied in broadcast form on the lane's column of L (trsvT_bcast); small models (nt <= 8) prefetch a knot ahead,
+// evaluate the model of G / nt knots at once on the group's idle lanes (KB) and, for short horizons, keep the factor in
+// LDS between the sweeps (LF: it is written to `fac` only from the step whose factor the caller keeps).
+//
 // HBM per Newton step and problem: xu, Qd, q (3 nz) + lam (ncon) in, update (nz) + banded factor
 // (T (nt^2 + nt n + nt)) out -- e.g. 6.6 KB at cartpole T = 20 against 177 KB for the dense path
 // (Jc written + read, L written).
