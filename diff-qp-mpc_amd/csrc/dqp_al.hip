@@ -692,10 +692,25 @@ __global__ __launch_bounds__(256) void al_ls_kernel(LsAP P)
 // problem's xu, upd, Qd, q and multipliers are loaded once into registers instead of once per
 // candidate, and the group is as wide as the horizon needs (TPI = 8, 16 or 32 lanes: one knot per lane in
 // the model phase -- with 16 lanes per candidate a T = 5 problem used 5 of them).
+// sum over a group of TPI lanes (aligned in the wavefront), in every lane of the group: DPP steps inside a 16-lane row
+// (a shuffle is a ds_bpermute round trip through the LDS crossbar, ~100 cycles each on the chain of a candidate), one
+// shuffle across the two rows of a 32-lane group
 template <int TPI> __device__ __forceinline__ double group_sum(double v)
 {
+    using dqp::r16::dppd;
+    if constexpr (TPI >= 16) {
+        v = dqp::r16::row_sum(v);
 #pragma unroll
-    for (int off = TPI / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        for (int off = 16; off < TPI; off <<= 1) v += __shfl_xor(v, off, 64);
+    } else if constexpr (TPI == 8) {
+        v += dppd<0x141>(v);        // row_half_mirror: l <-> 7 - l
+        v += dppd<0xb1>(v);         // quad_perm [1,0,3,2]
+        v += dppd<0x4e>(v);         // quad_perm [2,3,0,1]
+    } else {
+        static_assert(TPI == 4, "lane groups of 4, 8, 16 or 32");
+        v += dppd<0xb1>(v);
+        v += dppd<0x4e>(v);
+    }
     return v;
 }
 
